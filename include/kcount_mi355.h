@@ -1,0 +1,203 @@
+/*
+ * kcount_mi355.h -- C ABI of libkcount_mi355.so, the MI355X (gfx950) k-mer
+ * analysis stage that drops in behind MHM2's kcount / KmerDHT operator surface.
+ *
+ * Plain C: opaque handle, plain pointers and sizes, int status codes, no
+ * exceptions, no STL, no torch types.  Every entry point names the reference
+ * interface it replaces (paths relative to the reference checkout).  The C++
+ * adapters that re-create the reference's own driver classes on top of this
+ * ABI are in mhm2_kmer_analysis_v2_amd/csrc/kcount_driver.hpp; the binding a
+ * reference maintainer would add is shown in INTEGRATION.md.
+ *
+ * Semantics are those of the reference *CPU* backend (src/kcount/kcount_cpu.cpp),
+ * spec S1-S9 in SURVEY.md section 8a -- not the reference GPU backend, which
+ * differs from it (N handling, counter saturation).
+ */
+#ifndef KCOUNT_MI355_H
+#define KCOUNT_MI355_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define KC_ABI_VERSION 1
+
+/* status codes (all entry points returning int) */
+enum {
+  KC_OK = 0,
+  KC_ERR_INVALID_ARG = -1,
+  KC_ERR_UNSUPPORTED_K = -2, /* k < 3, k > 127, or k % 32 in {30, 31} (no room for the packed extension bits) */
+  KC_ERR_NO_DEVICE = -3,     /* HIP runtime reports no usable gfx950 device */
+  KC_ERR_HIP = -4,           /* a HIP call failed; kc_last_error() has the text */
+  KC_ERR_OUT_OF_MEMORY = -5,
+  KC_ERR_CAPACITY = -6,      /* caller-provided output buffer too small; nothing was changed, retry with more room */
+  KC_ERR_BAD_BASE = -7,      /* a read holds a byte outside ACGTN/acgtn (reference: DIE at kcount_cpu.cpp:484-486) */
+  KC_ERR_STATE = -8          /* call not allowed in this state (e.g. submit after finalize without reset) */
+};
+
+typedef struct kc_ctx kc_ctx;
+
+/*
+ * Run-time configuration.  Replaces the compile-time / CLI knobs the reference
+ * spreads over CMakeDefinitions.txt and src/options.cpp:
+ *   kmer_len     Options::kmer_lens                       src/options.hpp:80
+ *   qual_offset  Options::qual_offset, SeqBlockInserter   src/kcount/kcount.hpp:60
+ *   dmin_thres   --min-depth-thres, _dmin_thres           src/kcount/kmer_dht.hpp:57, src/kcount/kcount.cpp:146
+ *   rank_me/n    upcxx::rank_me()/rank_n() as passed to
+ *                HashTableGPUDriver::init                 src/kcount/kcount-gpu/gpu_hash_table.hpp:155
+ *   max_elems    init(max_elems, ..., num_errors, ...)    same; here: expected distinct k-mers of this shard
+ *                (0 = pick a default; the table grows instead of dropping inserts)
+ */
+typedef struct kc_config {
+  int32_t kmer_len;
+  int32_t qual_offset; /* 33 or 64 */
+  int32_t dmin_thres;  /* default 2 */
+  int32_t device;      /* HIP device ordinal */
+  int32_t rank_me;     /* this shard owns k-mers with kc_owner(key) == rank_me */
+  int32_t rank_n;      /* shards in the job (GPUs); 1 = everything local */
+  uint64_t max_elems;
+  uint32_t flags; /* KC_FLAG_* */
+  uint32_t reserved;
+} kc_config;
+
+#define KC_FLAG_NONE 0u
+
+/* Scalars the reference logs (src/kcount/kcount.cpp:94-102,158-160;
+ * src/kcount/kcount_cpu.cpp:495-521,586-598) plus table geometry. */
+typedef struct kc_stats {
+  uint64_t num_reads;
+  uint64_t num_bases;
+  uint64_t raw_kmers;      /* sum over reads of max(0, len-k+1): kcount.cpp:86 -- the unit of the k-mers/s metric */
+  uint64_t kmers_inserted; /* k-mer occurrences with both neighbours (S5) put into this shard's table */
+  uint64_t num_unique;     /* table entries before the purge */
+  uint64_t num_purged;     /* entries removed by S8 */
+  uint64_t total_kmers;    /* results: "Total kmers" */
+  uint64_t sum_counts;     /* "Total kmer count sum" */
+  uint64_t num_dropped;    /* always 0: the table grows; kept for the reference's precondition check */
+  uint64_t capacity;       /* table slots */
+  uint64_t num_gpu_calls;  /* kernel launches so far (HashTableGPUDriver::get_num_gpu_calls) */
+  uint64_t table_bytes;
+} kc_stats;
+
+/* Dense result arrays resident in HBM (replaces the compact KmerExtsMap the
+ * reference copies back slot by slot, gpu_hash_table.cpp:205-245,776-827, and
+ * the KmerCounts it becomes, kmer_dht.hpp:62-68).  Unordered, like a hash-map
+ * iteration; entry i is keys[i*num_longs .. +num_longs), counts[i], left[i],
+ * right[i] with left/right in "ACGT".  Pointers stay valid until kc_reset /
+ * kc_destroy. */
+typedef struct kc_result {
+  uint64_t n;
+  int32_t num_longs;
+  int32_t reserved;
+  const uint64_t *d_keys;
+  const uint16_t *d_counts;
+  const uint8_t *d_left;
+  const uint8_t *d_right;
+} kc_result;
+
+/* ---- library ------------------------------------------------------------ */
+int kc_abi_version(void);
+const char *kc_error_string(int status);
+const char *kc_last_error(void); /* text of the last failing HIP call on this thread */
+int kc_device_count(void);       /* 0 without a GPU; never aborts */
+
+/* Kmer<MAX_K>::N_LONGS for the MAX_K the reference would pick: k/32+1 (src/main.cpp:169-190, src/kmer.hpp:64). */
+int kc_num_longs(int kmer_len);
+/* Shard that owns a canonical k-mer (role of KmerDHT::get_kmer_target_rank,
+ * src/kcount/kmer_dht.cpp:192-196; any deterministic function of the k-mer
+ * gives the same final set).  Host-callable. */
+int kc_owner(const uint64_t *kmer_words, int kmer_len, int rank_n);
+
+/* ---- context ------------------------------------------------------------ */
+/* HashTableGPUDriver::init + ParseAndPackGPUDriver ctor (gpu_hash_table.cpp:522-624, parse_and_pack.cpp:239-267). */
+kc_ctx *kc_create(const kc_config *cfg, int *status);
+/* ~HashTableGPUDriver / ~ParseAndPackGPUDriver */
+void kc_destroy(kc_ctx *ctx);
+/* Launch everything on this hipStream_t (e.g. torch's current stream).  NULL = the context's own stream. */
+int kc_set_stream(kc_ctx *ctx, void *hip_stream);
+/* Empty the table and results but keep every allocation (multi-k sweeps with a new
+ * kmer_len re-use the arena; the reference re-allocates per run, F5 in SURVEY.md). */
+int kc_reset(kc_ctx *ctx, int new_kmer_len);
+
+/* ---- the hot path ------------------------------------------------------- */
+/*
+ * count_kmers' read loop + SeqBlockInserter::process_seq + the whole insert path
+ * for reads whose k-mers this shard owns (src/kcount/kcount.cpp:71-90,
+ * kcount_cpu.cpp:73-103,338-355).  bases/quals: concatenated ASCII, read r is
+ * [offsets[r], offsets[r+1]); quality mask S2 is applied on the device.
+ * on_device != 0: all three pointers are device pointers (HBM-resident input).
+ * With rank_n > 1 only k-mers owned by rank_me are inserted (use
+ * kc_extract_partition + kc_insert_records for the sharded flow).
+ */
+int kc_submit_reads(kc_ctx *ctx, const uint8_t *bases, const uint8_t *quals, const uint64_t *offsets, uint64_t nreads,
+                    int on_device);
+
+/*
+ * ParseAndPackGPUDriver::process_seq_block input format
+ * (src/kcount/kcount_gpu.cpp:167-180, parse_and_pack.cpp:281-319): reads already
+ * case-masked (lowercase = low quality) and joined by '_'.
+ */
+int kc_submit_seq_block(kc_ctx *ctx, const char *seqs, uint64_t len, int on_device);
+
+/*
+ * Sharded flow, sender side: extract k-mer records from a block of reads and
+ * bin them by owner shard (replaces parse_and_pack + build_supermers + the
+ * per-supermer ThreeTierAggrStore::update of kmer_dht.cpp:247-250).  Records of
+ * shard d land in d_records[d*seg_capacity*num_longs ...]; h_counts[d] receives
+ * how many.  A record is num_longs words: the canonical k-mer with the two
+ * extension codes in the low 6 bits of its last word (left | right<<3; 0-3 =
+ * ACGT, 4 = none).  KC_ERR_CAPACITY if a segment would overflow (nothing is lost:
+ * the table is untouched, call again with more room).
+ */
+int kc_extract_partition(kc_ctx *ctx, const uint8_t *bases, const uint8_t *quals, const uint64_t *offsets,
+                         uint64_t nreads, int on_device, uint64_t *d_records, uint64_t seg_capacity,
+                         uint64_t *h_counts);
+/* Receiver side: HashTableGPUDriver::insert_supermer/insert_supermer_block
+ * (gpu_hash_table.cpp:655-695) for records that arrived from other shards. */
+int kc_insert_records(kc_ctx *ctx, const uint64_t *d_records, uint64_t n);
+
+/* KmerDHT::flush_updates -> HashTableInserter::flush_inserts (kmer_dht.cpp:252-258): wait for submitted work. */
+int kc_flush(kc_ctx *ctx);
+
+/* HashTableGPUDriver::done_all_inserts + the S7/S8 pass of
+ * HashTableInserter::insert_into_local_hashtable (gpu_hash_table.cpp:736-784,
+ * kcount_cpu.cpp:523-601): vote, purge, compact.  out may be NULL. */
+int kc_finalize(kc_ctx *ctx, kc_result *out);
+/* begin_iterate/get_next_entry in bulk: copy the results to host arrays sized from kc_result.n. */
+int kc_copy_results(kc_ctx *ctx, uint64_t *keys, uint16_t *counts, uint8_t *left, uint8_t *right);
+/* Every table entry before the purge, for tests of S5/S6: keys[n*num_longs], counts[n] (clipped to 65535),
+ * exts[n*8] = left ACGT then right ACGT.  Call with NULLs to get n. */
+int kc_dump_table(kc_ctx *ctx, uint64_t *keys, uint16_t *counts, uint16_t *exts, uint64_t *n);
+
+int kc_get_stats(kc_ctx *ctx, kc_stats *out);
+
+/* ---- synthetic ArcticSynth-shaped reads (bench / tests) ------- */
+typedef struct kc_synth_params {
+  uint64_t seed;
+  uint32_t num_genomes;    /* default 64 */
+  uint32_t read_len;       /* default 150 */
+  uint64_t min_genome_len; /* default 2,000,000 */
+  uint64_t max_genome_len; /* default 6,000,000 */
+  double sub_error_rate;   /* default 0.005 */
+  double lowq_rate;        /* extra low-quality bases, default 0.01 */
+  double n_rate;           /* default 0 */
+  double abundance_sigma;  /* log-normal sigma, default 1.0 */
+} kc_synth_params;
+
+void kc_synth_default_params(kc_synth_params *p);
+/* Reads [first_read, first_read+nreads) of the stream defined by p, written as
+ * fixed-length records: bases/quals get nreads*read_len bytes, offsets nreads+1
+ * entries (relative to this block).  The host and device versions produce the
+ * same bytes. */
+int kc_synth_reads_host(const kc_synth_params *p, uint64_t first_read, uint64_t nreads, uint8_t *bases, uint8_t *quals,
+                        uint64_t *offsets);
+int kc_synth_reads_device(kc_ctx *ctx, const kc_synth_params *p, uint64_t first_read, uint64_t nreads, uint8_t *d_bases,
+                          uint8_t *d_quals, uint64_t *d_offsets);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* KCOUNT_MI355_H */

@@ -1,0 +1,97 @@
+"""ctypes binding of libkcount_mi355.so (include/kcount_mi355.h).  No fallback of any kind."""
+import ctypes as C
+import os
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+_LIB = None
+
+KC_OK = 0
+KC_ERR_CAPACITY = -6
+KC_ERR_BAD_BASE = -7
+
+
+class KcError(RuntimeError):
+    def __init__(self, status, where=""):
+        self.status = status
+        L = lib()
+        msg = L.kc_error_string(status).decode()
+        detail = L.kc_last_error().decode()
+        super().__init__("%s: %s (%d)%s" % (where, msg, status, (" -- " + detail) if detail and status in (-4, -5, -3) else ""))
+
+
+class kc_config(C.Structure):
+    _fields_ = [("kmer_len", C.c_int32), ("qual_offset", C.c_int32), ("dmin_thres", C.c_int32), ("device", C.c_int32),
+                ("rank_me", C.c_int32), ("rank_n", C.c_int32), ("max_elems", C.c_uint64), ("flags", C.c_uint32),
+                ("reserved", C.c_uint32)]
+
+
+class kc_stats(C.Structure):
+    _fields_ = [(n, C.c_uint64) for n in ("num_reads", "num_bases", "raw_kmers", "kmers_inserted", "num_unique", "num_purged",
+                                           "total_kmers", "sum_counts", "num_dropped", "capacity", "num_gpu_calls",
+                                           "table_bytes")]
+
+
+class kc_result(C.Structure):
+    _fields_ = [("n", C.c_uint64), ("num_longs", C.c_int32), ("reserved", C.c_int32), ("d_keys", C.c_void_p),
+                ("d_counts", C.c_void_p), ("d_left", C.c_void_p), ("d_right", C.c_void_p)]
+
+
+class kc_synth_params(C.Structure):
+    _fields_ = [("seed", C.c_uint64), ("num_genomes", C.c_uint32), ("read_len", C.c_uint32), ("min_genome_len", C.c_uint64),
+                ("max_genome_len", C.c_uint64), ("sub_error_rate", C.c_double), ("lowq_rate", C.c_double),
+                ("n_rate", C.c_double), ("abundance_sigma", C.c_double)]
+
+
+# every symbol include/kcount_mi355.h declares: (restype, argtypes)
+SYMBOLS = {
+    "kc_abi_version": (C.c_int, []),
+    "kc_error_string": (C.c_char_p, [C.c_int]),
+    "kc_last_error": (C.c_char_p, []),
+    "kc_device_count": (C.c_int, []),
+    "kc_num_longs": (C.c_int, [C.c_int]),
+    "kc_owner": (C.c_int, [C.c_void_p, C.c_int, C.c_int]),
+    "kc_create": (C.c_void_p, [C.POINTER(kc_config), C.POINTER(C.c_int)]),
+    "kc_destroy": (None, [C.c_void_p]),
+    "kc_set_stream": (C.c_int, [C.c_void_p, C.c_void_p]),
+    "kc_reset": (C.c_int, [C.c_void_p, C.c_int]),
+    "kc_submit_reads": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_uint64, C.c_int]),
+    "kc_submit_seq_block": (C.c_int, [C.c_void_p, C.c_void_p, C.c_uint64, C.c_int]),
+    "kc_extract_partition": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_uint64, C.c_int, C.c_void_p,
+                                       C.c_uint64, C.c_void_p]),
+    "kc_insert_records": (C.c_int, [C.c_void_p, C.c_void_p, C.c_uint64]),
+    "kc_flush": (C.c_int, [C.c_void_p]),
+    "kc_finalize": (C.c_int, [C.c_void_p, C.POINTER(kc_result)]),
+    "kc_copy_results": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]),
+    "kc_dump_table": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.POINTER(C.c_uint64)]),
+    "kc_get_stats": (C.c_int, [C.c_void_p, C.POINTER(kc_stats)]),
+    "kc_synth_default_params": (None, [C.POINTER(kc_synth_params)]),
+    "kc_synth_reads_host": (C.c_int, [C.POINTER(kc_synth_params), C.c_uint64, C.c_uint64, C.c_void_p, C.c_void_p, C.c_void_p]),
+    "kc_synth_reads_device": (C.c_int, [C.c_void_p, C.POINTER(kc_synth_params), C.c_uint64, C.c_uint64, C.c_void_p, C.c_void_p,
+                                        C.c_void_p]),
+}
+
+
+def lib_path():
+    return os.path.join(_HERE, "csrc", "libkcount_mi355.so")
+
+
+def lib():
+    """Load the HIP library.  Raises if it has not been built: there is no other implementation."""
+    global _LIB
+    if _LIB is None:
+        p = lib_path()
+        if not os.path.exists(p):
+            raise ImportError("%s is missing: run `python -c 'import __graft_entry__ as g; g.build()'` "
+                              "(or make -C mhm2_kmer_analysis_v2_amd/csrc); there is no CPU fallback" % p)
+        L = C.CDLL(p)
+        for name, (res, args) in SYMBOLS.items():
+            f = getattr(L, name)  # AttributeError if the .so does not export a declared symbol
+            f.restype = res
+            f.argtypes = args
+        _LIB = L
+    return _LIB
+
+
+def check(status, where):
+    if status != KC_OK:
+        raise KcError(status, where)

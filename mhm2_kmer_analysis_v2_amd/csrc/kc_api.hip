@@ -1,0 +1,768 @@
+// kc_api.hip -- host side of libkcount_mi355.so: the C ABI of include/kcount_mi355.h.
+//
+// Plays the role of the reference's two device drivers, ParseAndPackGPUDriver
+// (src/kcount/kcount-gpu/parse_and_pack.cpp:239-338) and HashTableGPUDriver
+// (src/kcount/kcount-gpu/gpu_hash_table.cpp:519-859), with the CPU backend's semantics.
+// No exceptions and no abort(): every failure is a status code (the reference aborts inside
+// UPC++ progress, src/gpu-utils/gpu_common.cpp:59-65).
+#include <hip/hip_runtime.h>
+
+#include <math.h>
+#include <stdio.h>
+#include <stdlib.h>
+#include <string.h>
+
+#include <algorithm>
+#include <new>
+#include <vector>
+
+#include "../../include/kcount_mi355.h"
+#include "kc_kernels.hpp"
+
+using namespace kc;
+
+static thread_local char g_last_error[512] = "";
+
+static int hip_fail(hipError_t e, const char *what, int line) {
+  snprintf(g_last_error, sizeof(g_last_error), "%s failed at kc_api.hip:%d: %s", what, line, hipGetErrorString(e));
+  return e == hipErrorOutOfMemory ? KC_ERR_OUT_OF_MEMORY : KC_ERR_HIP;
+}
+
+#define HIPCHK(call)                                          \
+  do {                                                        \
+    hipError_t e_ = (call);                                   \
+    if (e_ != hipSuccess) return hip_fail(e_, #call, __LINE__); \
+  } while (0)
+
+struct kc_ctx {
+  kc_config cfg;
+  int k, nl;
+  hipStream_t own_stream, stream;
+  // table arena: keys then vals
+  uint8_t *arena;
+  size_t arena_bytes;
+  uint64_t capacity;
+  Table table;
+  uint64_t *d_ctrs;
+  uint64_t *h_ctrs;  // pinned mirror
+  uint64_t *d_tile_first;
+  size_t tile_first_cap;
+  // staging for host-resident input
+  uint8_t *d_stage_bases, *d_stage_quals;
+  uint64_t *d_stage_offsets;
+  size_t stage_bytes, stage_reads;
+  // results
+  uint64_t *d_out_keys;
+  uint16_t *d_out_counts;
+  uint8_t *d_out_left, *d_out_right;
+  uint64_t out_cap, out_n;
+  bool finalized;
+  kc_synth_table *d_synth;
+  // host-side stats
+  uint64_t num_reads, num_bases, num_gpu_calls;
+  uint64_t purged, sum_counts, unique_at_finalize;
+};
+
+// ---- small helpers -----------------------------------------------------------------------------
+static uint64_t next_pow2(uint64_t v) {
+  uint64_t p = 1;
+  while (p < v) p <<= 1;
+  return p;
+}
+
+static size_t table_bytes_for(uint64_t capacity, int nl) { return (size_t)capacity * ((size_t)nl * 8 + 36); }
+
+static void carve_table(kc_ctx *c) {
+  c->table.keys = (uint64_t *)c->arena;
+  c->table.vals = (uint32_t *)(c->arena + (size_t)c->capacity * c->nl * 8);
+  c->table.mask = c->capacity - 1;
+}
+
+static int clear_table(kc_ctx *c) {
+  HIPCHK(hipMemsetAsync(c->table.keys, 0xFF, (size_t)c->capacity * c->nl * 8, c->stream));
+  HIPCHK(hipMemsetAsync(c->table.vals, 0, (size_t)c->capacity * 36, c->stream));
+  return KC_OK;
+}
+
+static int sync_ctrs(kc_ctx *c) {
+  HIPCHK(hipMemcpyAsync(c->h_ctrs, c->d_ctrs, CTR_COUNT * 8, hipMemcpyDeviceToHost, c->stream));
+  HIPCHK(hipStreamSynchronize(c->stream));
+  return KC_OK;
+}
+
+template <int NL>
+static int grow_table_nl(kc_ctx *c, uint64_t new_capacity) {
+  uint8_t *na = nullptr;
+  size_t nb = table_bytes_for(new_capacity, NL);
+  HIPCHK(hipMalloc((void **)&na, nb));
+  Table nt;
+  nt.keys = (uint64_t *)na;
+  nt.vals = (uint32_t *)(na + (size_t)new_capacity * NL * 8);
+  nt.mask = new_capacity - 1;
+  HIPCHK(hipMemsetAsync(nt.keys, 0xFF, (size_t)new_capacity * NL * 8, c->stream));
+  HIPCHK(hipMemsetAsync(nt.vals, 0, (size_t)new_capacity * 36, c->stream));
+  const uint64_t nblk = (c->capacity + 255) / 256;
+  hipLaunchKernelGGL(kc_rehash_kernel<NL>, dim3((unsigned)nblk), dim3(256), 0, c->stream, c->table, c->capacity, nt);
+  c->num_gpu_calls++;
+  HIPCHK(hipGetLastError());
+  HIPCHK(hipStreamSynchronize(c->stream));
+  HIPCHK(hipFree(c->arena));
+  c->arena = na;
+  c->arena_bytes = nb;
+  c->capacity = new_capacity;
+  c->table = nt;
+  return KC_OK;
+}
+
+static int grow_table(kc_ctx *c, uint64_t new_capacity) {
+  switch (c->nl) {
+    case 1: return grow_table_nl<1>(c, new_capacity);
+    case 2: return grow_table_nl<2>(c, new_capacity);
+    case 3: return grow_table_nl<3>(c, new_capacity);
+    default: return grow_table_nl<4>(c, new_capacity);
+  }
+}
+
+// make sure `incoming` more distinct k-mers keep the load below 0.9 (syncs the stream)
+static int ensure_room(kc_ctx *c, uint64_t incoming) {
+  int rc = sync_ctrs(c);
+  if (rc) return rc;
+  if (c->h_ctrs[CTR_BAD_BASE]) return KC_ERR_BAD_BASE;
+  uint64_t need = c->h_ctrs[CTR_ENTRIES] + incoming;
+  uint64_t cap = c->capacity;
+  while ((double)need > 0.9 * (double)cap) cap <<= 1;
+  if (cap != c->capacity) return grow_table(c, cap);
+  return KC_OK;
+}
+
+static int ensure_tile_first(kc_ctx *c, size_t ntiles) {
+  if (ntiles <= c->tile_first_cap) return KC_OK;
+  if (c->d_tile_first) HIPCHK(hipFree(c->d_tile_first));
+  c->d_tile_first = nullptr;
+  c->tile_first_cap = 0;
+  HIPCHK(hipMalloc((void **)&c->d_tile_first, ntiles * 8));
+  c->tile_first_cap = ntiles;
+  return KC_OK;
+}
+
+// ---- library -----------------------------------------------------------------------------------
+extern "C" int kc_abi_version(void) { return KC_ABI_VERSION; }
+
+extern "C" const char *kc_error_string(int s) {
+  switch (s) {
+    case KC_OK: return "ok";
+    case KC_ERR_INVALID_ARG: return "invalid argument";
+    case KC_ERR_UNSUPPORTED_K: return "unsupported k-mer length";
+    case KC_ERR_NO_DEVICE: return "no usable HIP device";
+    case KC_ERR_HIP: return "HIP call failed";
+    case KC_ERR_OUT_OF_MEMORY: return "out of device memory";
+    case KC_ERR_CAPACITY: return "output buffer too small";
+    case KC_ERR_BAD_BASE: return "read holds a byte outside ACGTN";
+    case KC_ERR_STATE: return "call not allowed in this state";
+    default: return "unknown status";
+  }
+}
+
+extern "C" const char *kc_last_error(void) { return g_last_error; }
+
+extern "C" int kc_device_count(void) {
+  int n = 0;
+  if (hipGetDeviceCount(&n) != hipSuccess) return 0;
+  return n;
+}
+
+extern "C" int kc_num_longs(int k) { return k / 32 + 1; }
+
+static int check_k(int k) {
+  if (k < 3 || k > 127) return KC_ERR_UNSUPPORTED_K;
+  int m = k % 32;
+  if (m == 30 || m == 31) return KC_ERR_UNSUPPORTED_K;  // the last word has no 6 spare bits
+  return KC_OK;
+}
+
+extern "C" int kc_owner(const uint64_t *w, int k, int rank_n) {
+  if (!w || check_k(k) || rank_n < 1) return KC_ERR_INVALID_ARG;
+  uint64_t h;
+  switch (kc_num_longs(k)) {
+    case 1: { uint64_t a[1] = {w[0]}; h = kc_hash<1>(a); break; }
+    case 2: { uint64_t a[2] = {w[0], w[1]}; h = kc_hash<2>(a); break; }
+    case 3: { uint64_t a[3] = {w[0], w[1], w[2]}; h = kc_hash<3>(a); break; }
+    default: { uint64_t a[4] = {w[0], w[1], w[2], w[3]}; h = kc_hash<4>(a); break; }
+  }
+  return (int)kc_owner_of_hash(h, (uint32_t)rank_n);
+}
+
+// ---- context -----------------------------------------------------------------------------------
+static int create_impl(kc_ctx *c) {
+  HIPCHK(hipSetDevice(c->cfg.device));
+  HIPCHK(hipStreamCreateWithFlags(&c->own_stream, hipStreamNonBlocking));
+  c->stream = c->own_stream;
+  uint64_t want = c->cfg.max_elems ? c->cfg.max_elems : (1ULL << 24);
+  c->capacity = next_pow2((uint64_t)((double)want / 0.6) + 1);
+  if (c->capacity < (1ULL << 16)) c->capacity = 1ULL << 16;
+  c->arena_bytes = table_bytes_for(c->capacity, c->nl);
+  HIPCHK(hipMalloc((void **)&c->arena, c->arena_bytes));
+  carve_table(c);
+  HIPCHK(hipMalloc((void **)&c->d_ctrs, CTR_COUNT * 8));
+  HIPCHK(hipHostMalloc((void **)&c->h_ctrs, CTR_COUNT * 8, hipHostMallocDefault));
+  HIPCHK(hipMemsetAsync(c->d_ctrs, 0, CTR_COUNT * 8, c->stream));
+  int rc = clear_table(c);
+  if (rc) return rc;
+  HIPCHK(hipStreamSynchronize(c->stream));
+  return KC_OK;
+}
+
+extern "C" kc_ctx *kc_create(const kc_config *cfg, int *status) {
+  int st = KC_OK;
+  kc_ctx *c = nullptr;
+  if (!cfg || cfg->rank_n < 1 || cfg->rank_n > 64 || cfg->rank_me < 0 || cfg->rank_me >= cfg->rank_n) st = KC_ERR_INVALID_ARG;
+  if (!st) st = check_k(cfg->kmer_len);
+  if (!st && (cfg->device < 0 || cfg->device >= kc_device_count())) {
+    st = KC_ERR_NO_DEVICE;
+    snprintf(g_last_error, sizeof(g_last_error), "device %d requested, %d visible", cfg->device, kc_device_count());
+  }
+  if (!st) {
+    c = new (std::nothrow) kc_ctx();
+    if (!c) st = KC_ERR_OUT_OF_MEMORY;
+  }
+  if (!st) {
+    memset(c, 0, sizeof(*c));
+    c->cfg = *cfg;
+    if (c->cfg.dmin_thres <= 0) c->cfg.dmin_thres = 2;
+    c->k = cfg->kmer_len;
+    c->nl = kc_num_longs(c->k);
+    st = create_impl(c);
+    if (st) {
+      kc_destroy(c);
+      c = nullptr;
+    }
+  }
+  if (status) *status = st;
+  return c;
+}
+
+static void free_results(kc_ctx *c) {
+  if (c->d_out_keys) (void)hipFree(c->d_out_keys);
+  if (c->d_out_counts) (void)hipFree(c->d_out_counts);
+  if (c->d_out_left) (void)hipFree(c->d_out_left);
+  if (c->d_out_right) (void)hipFree(c->d_out_right);
+  c->d_out_keys = nullptr;
+  c->d_out_counts = nullptr;
+  c->d_out_left = c->d_out_right = nullptr;
+  c->out_cap = c->out_n = 0;
+}
+
+extern "C" void kc_destroy(kc_ctx *c) {
+  if (!c) return;
+  (void)hipSetDevice(c->cfg.device);
+  if (c->stream) (void)hipStreamSynchronize(c->stream);
+  free_results(c);
+  if (c->arena) (void)hipFree(c->arena);
+  if (c->d_ctrs) (void)hipFree(c->d_ctrs);
+  if (c->h_ctrs) (void)hipHostFree(c->h_ctrs);
+  if (c->d_tile_first) (void)hipFree(c->d_tile_first);
+  if (c->d_stage_bases) (void)hipFree(c->d_stage_bases);
+  if (c->d_stage_quals) (void)hipFree(c->d_stage_quals);
+  if (c->d_stage_offsets) (void)hipFree(c->d_stage_offsets);
+  if (c->d_synth) (void)hipFree(c->d_synth);
+  if (c->own_stream) (void)hipStreamDestroy(c->own_stream);
+  delete c;
+}
+
+extern "C" int kc_set_stream(kc_ctx *c, void *s) {
+  if (!c) return KC_ERR_INVALID_ARG;
+  HIPCHK(hipStreamSynchronize(c->stream));
+  c->stream = s ? (hipStream_t)s : c->own_stream;
+  return KC_OK;
+}
+
+extern "C" int kc_reset(kc_ctx *c, int new_k) {
+  if (!c) return KC_ERR_INVALID_ARG;
+  if (new_k == 0) new_k = c->k;
+  int st = check_k(new_k);
+  if (st) return st;
+  HIPCHK(hipSetDevice(c->cfg.device));
+  HIPCHK(hipStreamSynchronize(c->stream));
+  free_results(c);
+  c->k = new_k;
+  c->cfg.kmer_len = new_k;
+  c->nl = kc_num_longs(new_k);
+  // re-carve the same arena for the new word count: largest power of two that fits
+  uint64_t cap = 1;
+  while (table_bytes_for(cap << 1, c->nl) <= c->arena_bytes) cap <<= 1;
+  c->capacity = cap;
+  carve_table(c);
+  HIPCHK(hipMemsetAsync(c->d_ctrs, 0, CTR_COUNT * 8, c->stream));
+  st = clear_table(c);
+  if (st) return st;
+  c->finalized = false;
+  c->num_reads = c->num_bases = 0;
+  c->purged = c->sum_counts = c->unique_at_finalize = 0;
+  HIPCHK(hipStreamSynchronize(c->stream));
+  return KC_OK;
+}
+
+// ---- extraction launches -----------------------------------------------------------------------
+template <int NL, int MODE, int FMT>
+static void launch_extract_t(kc_ctx *c, const ExtractArgs &a, unsigned ntiles) {
+  hipLaunchKernelGGL((kc_extract_kernel<NL, MODE, FMT>), dim3(ntiles), dim3(TPB), 0, c->stream, a, c->table, c->d_ctrs);
+}
+
+template <int MODE, int FMT>
+static void launch_extract_m(kc_ctx *c, const ExtractArgs &a, unsigned ntiles) {
+  switch (c->nl) {
+    case 1: launch_extract_t<1, MODE, FMT>(c, a, ntiles); break;
+    case 2: launch_extract_t<2, MODE, FMT>(c, a, ntiles); break;
+    case 3: launch_extract_t<3, MODE, FMT>(c, a, ntiles); break;
+    default: launch_extract_t<4, MODE, FMT>(c, a, ntiles); break;
+  }
+}
+
+static void launch_extract(kc_ctx *c, const ExtractArgs &a, unsigned ntiles, int mode, int fmt) {
+  if (mode == MODE_INSERT) {
+    if (fmt == FMT_READS) launch_extract_m<MODE_INSERT, FMT_READS>(c, a, ntiles);
+    else launch_extract_m<MODE_INSERT, FMT_SEQBLOCK>(c, a, ntiles);
+  } else {
+    if (fmt == FMT_READS) launch_extract_m<MODE_BIN, FMT_READS>(c, a, ntiles);
+    else launch_extract_m<MODE_BIN, FMT_SEQBLOCK>(c, a, ntiles);
+  }
+  c->num_gpu_calls++;
+}
+
+// One block of device-resident input through the extract kernel, in chunks of tiles.
+static int run_extract_device(kc_ctx *c, const uint8_t *bases, const uint8_t *quals, const uint64_t *d_offsets, uint64_t nreads,
+                              uint64_t total, int mode, int fmt, uint64_t *d_records, uint64_t seg_capacity) {
+  if (total == 0) return KC_OK;
+  ExtractArgs a;
+  memset(&a, 0, sizeof(a));
+  a.align = (uint32_t)((uintptr_t)bases & 15u);
+  a.bases = bases - a.align;
+  if (fmt == FMT_READS) {
+    a.quals = quals - a.align;
+    a.quals_vector_ok = (((uintptr_t)a.quals & 15u) == 0) ? 1u : 0u;
+    a.offsets = d_offsets;
+  }
+  a.nreads = nreads;
+  a.total = total;
+  a.k = c->k;
+  a.qual_cut = c->cfg.qual_offset + KC_QUAL_CUTOFF;
+  a.rank_me = (uint32_t)c->cfg.rank_me;
+  a.rank_n = (uint32_t)c->cfg.rank_n;
+  a.records = d_records;
+  a.seg_capacity = seg_capacity;
+  const uint64_t ntiles_total = (a.align + total + TILE - 1) / TILE;
+  uint64_t t0 = 0;
+  while (t0 < ntiles_total) {
+    // a chunk may add at most one new entry per position: keep it within a quarter of the table
+    uint64_t chunk_tiles = std::max<uint64_t>(64, (c->capacity / 4) / TILE);
+    chunk_tiles = std::min<uint64_t>(chunk_tiles, (1ULL << 28) / TILE);
+    uint64_t nt = std::min(chunk_tiles, ntiles_total - t0);
+    if (mode == MODE_INSERT) {
+      int rc = ensure_room(c, nt * TILE);
+      if (rc) return rc;
+    }
+    if (fmt == FMT_READS) {
+      int rc = ensure_tile_first(c, nt);
+      if (rc) return rc;
+      hipLaunchKernelGGL(kc_tile_first_kernel, dim3((unsigned)((nt + 255) / 256)), dim3(256), 0, c->stream, d_offsets, nreads,
+                         a.align, t0, nt, c->d_tile_first);
+      c->num_gpu_calls++;
+      a.tile_first = c->d_tile_first;
+    }
+    a.tile0 = t0;
+    launch_extract(c, a, (unsigned)nt, mode, fmt);
+    HIPCHK(hipGetLastError());
+    t0 += nt;
+  }
+  return KC_OK;
+}
+
+static int raw_kmer_stats(kc_ctx *c, const uint64_t *d_offsets, uint64_t nreads) {
+  if (!nreads) return KC_OK;
+  unsigned nblk = (unsigned)std::min<uint64_t>((nreads + 255) / 256, 4096);
+  hipLaunchKernelGGL(kc_read_stats_kernel, dim3(nblk), dim3(256), 0, c->stream, d_offsets, nreads, c->k, c->d_ctrs);
+  c->num_gpu_calls++;
+  HIPCHK(hipGetLastError());
+  return KC_OK;
+}
+
+static int ensure_stage(kc_ctx *c, size_t bytes, size_t reads, bool need_quals) {
+  if (bytes + 64 > c->stage_bytes) {
+    if (c->d_stage_bases) HIPCHK(hipFree(c->d_stage_bases));
+    if (c->d_stage_quals) HIPCHK(hipFree(c->d_stage_quals));
+    c->d_stage_bases = c->d_stage_quals = nullptr;
+    c->stage_bytes = 0;
+    HIPCHK(hipMalloc((void **)&c->d_stage_bases, bytes + 64));
+    HIPCHK(hipMalloc((void **)&c->d_stage_quals, bytes + 64));
+    c->stage_bytes = bytes + 64;
+  }
+  (void)need_quals;
+  if (reads + 1 > c->stage_reads) {
+    if (c->d_stage_offsets) HIPCHK(hipFree(c->d_stage_offsets));
+    c->d_stage_offsets = nullptr;
+    c->stage_reads = 0;
+    HIPCHK(hipMalloc((void **)&c->d_stage_offsets, (reads + 1) * 8));
+    c->stage_reads = reads + 1;
+  }
+  return KC_OK;
+}
+
+// reads (either residence) through extract in `mode`
+static int submit_reads_impl(kc_ctx *c, const uint8_t *bases, const uint8_t *quals, const uint64_t *offsets, uint64_t nreads,
+                             int on_device, int mode, uint64_t *d_records, uint64_t seg_capacity) {
+  if (!c || (nreads && (!bases || !quals || !offsets))) return KC_ERR_INVALID_ARG;
+  if (c->finalized) return KC_ERR_STATE;
+  HIPCHK(hipSetDevice(c->cfg.device));
+  if (!nreads) return KC_OK;
+  if (on_device) {
+    uint64_t ends[2];
+    HIPCHK(hipMemcpyAsync(&ends[0], offsets, 8, hipMemcpyDeviceToHost, c->stream));
+    HIPCHK(hipMemcpyAsync(&ends[1], offsets + nreads, 8, hipMemcpyDeviceToHost, c->stream));
+    HIPCHK(hipStreamSynchronize(c->stream));
+    if (ends[0] != 0) return KC_ERR_INVALID_ARG;  // offsets are relative to `bases`
+    int rc = raw_kmer_stats(c, offsets, nreads);
+    if (rc) return rc;
+    rc = run_extract_device(c, bases, quals, offsets, nreads, ends[1], mode, FMT_READS, d_records, seg_capacity);
+    if (rc) return rc;
+    c->num_reads += nreads;
+    c->num_bases += ends[1];
+    return KC_OK;
+  }
+  // host-resident: stage blocks of whole reads
+  const size_t BLOCK = 64u << 20;
+  std::vector<uint64_t> rel;
+  uint64_t r0 = 0;
+  while (r0 < nreads) {
+    uint64_t r1 = r0 + 1;
+    while (r1 < nreads && offsets[r1 + 1] - offsets[r0] <= BLOCK) r1++;
+    const uint64_t nb = offsets[r1] - offsets[r0], nr = r1 - r0;
+    int rc = ensure_stage(c, (size_t)nb, (size_t)nr, true);
+    if (rc) return rc;
+    rel.resize(nr + 1);
+    for (uint64_t i = 0; i <= nr; i++) rel[i] = offsets[r0 + i] - offsets[r0];
+    // the previous block's kernels may still be reading the staging buffers
+    HIPCHK(hipStreamSynchronize(c->stream));
+    HIPCHK(hipMemcpyAsync(c->d_stage_bases, bases + offsets[r0], nb, hipMemcpyHostToDevice, c->stream));
+    HIPCHK(hipMemcpyAsync(c->d_stage_quals, quals + offsets[r0], nb, hipMemcpyHostToDevice, c->stream));
+    HIPCHK(hipMemcpyAsync(c->d_stage_offsets, rel.data(), (nr + 1) * 8, hipMemcpyHostToDevice, c->stream));
+    HIPCHK(hipStreamSynchronize(c->stream));  // rel is reused next trip
+    rc = raw_kmer_stats(c, c->d_stage_offsets, nr);
+    if (rc) return rc;
+    rc = run_extract_device(c, c->d_stage_bases, c->d_stage_quals, c->d_stage_offsets, nr, nb, mode, FMT_READS, d_records,
+                            seg_capacity);
+    if (rc) return rc;
+    c->num_reads += nr;
+    c->num_bases += nb;
+    r0 = r1;
+  }
+  return KC_OK;
+}
+
+extern "C" int kc_submit_reads(kc_ctx *c, const uint8_t *bases, const uint8_t *quals, const uint64_t *offsets, uint64_t nreads,
+                               int on_device) {
+  return submit_reads_impl(c, bases, quals, offsets, nreads, on_device, MODE_INSERT, nullptr, 0);
+}
+
+extern "C" int kc_submit_seq_block(kc_ctx *c, const char *seqs, uint64_t len, int on_device) {
+  if (!c || (len && !seqs)) return KC_ERR_INVALID_ARG;
+  if (c->finalized) return KC_ERR_STATE;
+  HIPCHK(hipSetDevice(c->cfg.device));
+  if (!len) return KC_OK;
+  const uint8_t *d = (const uint8_t *)seqs;
+  if (!on_device) {
+    int rc = ensure_stage(c, (size_t)len, 0, false);
+    if (rc) return rc;
+    HIPCHK(hipStreamSynchronize(c->stream));
+    HIPCHK(hipMemcpyAsync(c->d_stage_bases, seqs, len, hipMemcpyHostToDevice, c->stream));
+    d = c->d_stage_bases;
+  }
+  unsigned nblk = (unsigned)std::min<uint64_t>((len + 255) / 256, 4096);
+  hipLaunchKernelGGL(kc_seqblock_stats_kernel, dim3(nblk), dim3(256), 0, c->stream, d, len, c->k, c->d_ctrs);
+  c->num_gpu_calls++;
+  int rc = run_extract_device(c, d, nullptr, nullptr, 0, len, MODE_INSERT, FMT_SEQBLOCK, nullptr, 0);
+  if (rc) return rc;
+  c->num_bases += len;
+  if (!on_device) HIPCHK(hipStreamSynchronize(c->stream));  // caller's buffer is free to change
+  return KC_OK;
+}
+
+extern "C" int kc_extract_partition(kc_ctx *c, const uint8_t *bases, const uint8_t *quals, const uint64_t *offsets, uint64_t nreads,
+                                    int on_device, uint64_t *d_records, uint64_t seg_capacity, uint64_t *h_counts) {
+  if (!c || !h_counts || (nreads && !d_records)) return KC_ERR_INVALID_ARG;
+  HIPCHK(hipSetDevice(c->cfg.device));
+  HIPCHK(hipMemsetAsync(c->d_ctrs + CTR_OVERFLOW, 0, (1 + 64) * 8, c->stream));
+  int rc = submit_reads_impl(c, bases, quals, offsets, nreads, on_device, MODE_BIN, d_records, seg_capacity);
+  if (rc) return rc;
+  rc = sync_ctrs(c);
+  if (rc) return rc;
+  for (int d = 0; d < c->cfg.rank_n; d++) h_counts[d] = c->h_ctrs[CTR_BIN0 + d];
+  if (c->h_ctrs[CTR_BAD_BASE]) return KC_ERR_BAD_BASE;
+  if (c->h_ctrs[CTR_OVERFLOW]) return KC_ERR_CAPACITY;
+  return KC_OK;
+}
+
+template <int NL>
+static void launch_insert_records(kc_ctx *c, const uint64_t *recs, uint64_t n) {
+  unsigned nblk = (unsigned)std::min<uint64_t>((n + TPB - 1) / TPB, 256 * 32);
+  hipLaunchKernelGGL(kc_insert_records_kernel<NL>, dim3(nblk), dim3(TPB), 0, c->stream, recs, n, c->table, c->d_ctrs);
+}
+
+extern "C" int kc_insert_records(kc_ctx *c, const uint64_t *d_records, uint64_t n) {
+  if (!c || (n && !d_records)) return KC_ERR_INVALID_ARG;
+  if (c->finalized) return KC_ERR_STATE;
+  HIPCHK(hipSetDevice(c->cfg.device));
+  uint64_t done = 0;
+  while (done < n) {
+    uint64_t m = std::min<uint64_t>(n - done, std::max<uint64_t>(c->capacity / 4, 1u << 18));
+    int rc = ensure_room(c, m);
+    if (rc) return rc;
+    const uint64_t *p = d_records + done * c->nl;
+    switch (c->nl) {
+      case 1: launch_insert_records<1>(c, p, m); break;
+      case 2: launch_insert_records<2>(c, p, m); break;
+      case 3: launch_insert_records<3>(c, p, m); break;
+      default: launch_insert_records<4>(c, p, m); break;
+    }
+    c->num_gpu_calls++;
+    HIPCHK(hipGetLastError());
+    done += m;
+  }
+  return KC_OK;
+}
+
+extern "C" int kc_flush(kc_ctx *c) {
+  if (!c) return KC_ERR_INVALID_ARG;
+  HIPCHK(hipSetDevice(c->cfg.device));
+  int rc = sync_ctrs(c);
+  if (rc) return rc;
+  if (c->h_ctrs[CTR_BAD_BASE]) return KC_ERR_BAD_BASE;
+  return KC_OK;
+}
+
+// ---- finalize ----------------------------------------------------------------------------------
+template <int NL>
+static void launch_finalize(kc_ctx *c) {
+  unsigned nblk = (unsigned)std::min<uint64_t>((c->capacity + TPB - 1) / TPB, 256 * 16);
+  hipLaunchKernelGGL(kc_finalize_kernel<NL>, dim3(nblk), dim3(TPB), 0, c->stream, c->table, c->capacity, c->cfg.dmin_thres,
+                     c->d_out_keys, c->d_out_counts, c->d_out_left, c->d_out_right, c->d_ctrs);
+}
+
+extern "C" int kc_finalize(kc_ctx *c, kc_result *out) {
+  if (!c) return KC_ERR_INVALID_ARG;
+  HIPCHK(hipSetDevice(c->cfg.device));
+  if (!c->finalized) {
+    int rc = sync_ctrs(c);
+    if (rc) return rc;
+    if (c->h_ctrs[CTR_BAD_BASE]) return KC_ERR_BAD_BASE;
+    const uint64_t entries = c->h_ctrs[CTR_ENTRIES];
+    free_results(c);
+    const uint64_t cap = entries ? entries : 1;
+    HIPCHK(hipMalloc((void **)&c->d_out_keys, cap * c->nl * 8));
+    HIPCHK(hipMalloc((void **)&c->d_out_counts, cap * 2));
+    HIPCHK(hipMalloc((void **)&c->d_out_left, cap));
+    HIPCHK(hipMalloc((void **)&c->d_out_right, cap));
+    c->out_cap = cap;
+    HIPCHK(hipMemsetAsync(c->d_ctrs + CTR_OUT, 0, 3 * 8, c->stream));  // OUT, PURGED, SUM_COUNTS
+    switch (c->nl) {
+      case 1: launch_finalize<1>(c); break;
+      case 2: launch_finalize<2>(c); break;
+      case 3: launch_finalize<3>(c); break;
+      default: launch_finalize<4>(c); break;
+    }
+    c->num_gpu_calls++;
+    HIPCHK(hipGetLastError());
+    rc = sync_ctrs(c);
+    if (rc) return rc;
+    c->out_n = c->h_ctrs[CTR_OUT];
+    c->purged = c->h_ctrs[CTR_PURGED];
+    c->sum_counts = c->h_ctrs[CTR_SUM_COUNTS];
+    c->unique_at_finalize = entries;
+    c->finalized = true;
+  }
+  if (out) {
+    out->n = c->out_n;
+    out->num_longs = c->nl;
+    out->reserved = 0;
+    out->d_keys = c->d_out_keys;
+    out->d_counts = c->d_out_counts;
+    out->d_left = c->d_out_left;
+    out->d_right = c->d_out_right;
+  }
+  return KC_OK;
+}
+
+extern "C" int kc_copy_results(kc_ctx *c, uint64_t *keys, uint16_t *counts, uint8_t *left, uint8_t *right) {
+  if (!c) return KC_ERR_INVALID_ARG;
+  if (!c->finalized) return KC_ERR_STATE;
+  HIPCHK(hipSetDevice(c->cfg.device));
+  const uint64_t n = c->out_n;
+  if (!n) return KC_OK;
+  if (keys) HIPCHK(hipMemcpy(keys, c->d_out_keys, n * c->nl * 8, hipMemcpyDeviceToHost));
+  if (counts) HIPCHK(hipMemcpy(counts, c->d_out_counts, n * 2, hipMemcpyDeviceToHost));
+  if (left) HIPCHK(hipMemcpy(left, c->d_out_left, n, hipMemcpyDeviceToHost));
+  if (right) HIPCHK(hipMemcpy(right, c->d_out_right, n, hipMemcpyDeviceToHost));
+  return KC_OK;
+}
+
+extern "C" int kc_dump_table(kc_ctx *c, uint64_t *keys, uint16_t *counts, uint16_t *exts, uint64_t *n_out) {
+  if (!c || !n_out) return KC_ERR_INVALID_ARG;
+  HIPCHK(hipSetDevice(c->cfg.device));
+  int rc = sync_ctrs(c);
+  if (rc) return rc;
+  const uint64_t n = c->h_ctrs[CTR_ENTRIES];
+  *n_out = n;
+  if (!keys || !n) return KC_OK;
+  uint64_t *dk = nullptr, *dcur = nullptr;
+  uint16_t *dc = nullptr, *de = nullptr;
+  HIPCHK(hipMalloc((void **)&dk, n * c->nl * 8));
+  HIPCHK(hipMalloc((void **)&dc, n * 2));
+  HIPCHK(hipMalloc((void **)&de, n * 16));
+  HIPCHK(hipMalloc((void **)&dcur, 8));
+  HIPCHK(hipMemsetAsync(dcur, 0, 8, c->stream));
+  const unsigned nblk = (unsigned)((c->capacity + 255) / 256);
+  switch (c->nl) {
+    case 1: hipLaunchKernelGGL(kc_dump_kernel<1>, dim3(nblk), dim3(256), 0, c->stream, c->table, c->capacity, dk, dc, de, dcur); break;
+    case 2: hipLaunchKernelGGL(kc_dump_kernel<2>, dim3(nblk), dim3(256), 0, c->stream, c->table, c->capacity, dk, dc, de, dcur); break;
+    case 3: hipLaunchKernelGGL(kc_dump_kernel<3>, dim3(nblk), dim3(256), 0, c->stream, c->table, c->capacity, dk, dc, de, dcur); break;
+    default: hipLaunchKernelGGL(kc_dump_kernel<4>, dim3(nblk), dim3(256), 0, c->stream, c->table, c->capacity, dk, dc, de, dcur); break;
+  }
+  c->num_gpu_calls++;
+  HIPCHK(hipGetLastError());
+  HIPCHK(hipStreamSynchronize(c->stream));
+  HIPCHK(hipMemcpy(keys, dk, n * c->nl * 8, hipMemcpyDeviceToHost));
+  HIPCHK(hipMemcpy(counts, dc, n * 2, hipMemcpyDeviceToHost));
+  HIPCHK(hipMemcpy(exts, de, n * 16, hipMemcpyDeviceToHost));
+  (void)hipFree(dk);
+  (void)hipFree(dc);
+  (void)hipFree(de);
+  (void)hipFree(dcur);
+  return KC_OK;
+}
+
+extern "C" int kc_get_stats(kc_ctx *c, kc_stats *o) {
+  if (!c || !o) return KC_ERR_INVALID_ARG;
+  HIPCHK(hipSetDevice(c->cfg.device));
+  int rc = sync_ctrs(c);
+  if (rc) return rc;
+  memset(o, 0, sizeof(*o));
+  o->num_reads = c->num_reads;
+  o->num_bases = c->num_bases;
+  o->raw_kmers = c->h_ctrs[CTR_RAW_KMERS];
+  o->kmers_inserted = c->h_ctrs[CTR_INSERTED];
+  o->num_unique = c->h_ctrs[CTR_ENTRIES];
+  o->num_purged = c->purged;
+  o->total_kmers = c->out_n;
+  o->sum_counts = c->sum_counts;
+  o->num_dropped = 0;
+  o->capacity = c->capacity;
+  o->num_gpu_calls = c->num_gpu_calls;
+  o->table_bytes = c->arena_bytes;
+  return KC_OK;
+}
+
+// ---- synthetic reads ---------------------------------------------------------------------------
+extern "C" void kc_synth_default_params(kc_synth_params *p) {
+  if (!p) return;
+  p->seed = 1234;
+  p->num_genomes = 64;
+  p->read_len = 150;
+  p->min_genome_len = 2000000;
+  p->max_genome_len = 6000000;
+  p->sub_error_rate = 0.005;
+  p->lowq_rate = 0.01;
+  p->n_rate = 0.0;
+  p->abundance_sigma = 1.0;
+}
+
+static uint64_t rate_to_thr(double r) {
+  if (r <= 0) return 0;
+  if (r >= 1) return ~0ULL;
+  return (uint64_t)((long double)r * 18446744073709551616.0L);
+}
+
+static int build_synth_table(const kc_synth_params *p, kc_synth_table *t) {
+  if (!p || p->num_genomes < 1 || p->num_genomes > KC_SYNTH_MAX_GENOMES || p->read_len < 1 || p->min_genome_len < p->read_len ||
+      p->max_genome_len < p->min_genome_len)
+    return KC_ERR_INVALID_ARG;
+  memset(t, 0, sizeof(*t));
+  t->seed = p->seed;
+  t->num_genomes = p->num_genomes;
+  t->read_len = p->read_len;
+  t->err_thr = rate_to_thr(p->sub_error_rate);
+  t->lowq_thr = rate_to_thr(p->sub_error_rate + p->lowq_rate);
+  t->n_thr = rate_to_thr(p->n_rate);
+  std::vector<long double> w(p->num_genomes);
+  long double tot = 0;
+  for (uint32_t g = 0; g < p->num_genomes; g++) {
+    uint64_t s = kc_splitmix(p->seed * 0x2545F4914F6CDD1DULL + g);
+    t->genome_len[g] = p->min_genome_len + s % (p->max_genome_len - p->min_genome_len + 1);
+    t->genome_seed[g] = kc_splitmix(s ^ 0x5851F42D4C957F2DULL);
+    // log-normal abundance (seed+1 stream), Box-Muller
+    uint64_t a = kc_splitmix((p->seed + 1) * 0x9E3779B97F4A7C15ULL + 2 * g), b = kc_splitmix((p->seed + 1) * 0x9E3779B97F4A7C15ULL + 2 * g + 1);
+    double u1 = ((double)(a >> 11) + 1.0) / 9007199254740993.0, u2 = (double)(b >> 11) / 9007199254740992.0;
+    double z = sqrt(-2.0 * log(u1)) * cos(6.283185307179586 * u2);
+    w[g] = (long double)exp(p->abundance_sigma * z) * (long double)t->genome_len[g];
+    tot += w[g];
+  }
+  long double acc = 0;
+  for (uint32_t g = 0; g < p->num_genomes; g++) {
+    acc += w[g];
+    long double f = acc / tot;
+    t->cum[g] = (f >= 1.0L) ? ~0ULL : (uint64_t)(f * 18446744073709551615.0L);
+  }
+  t->cum[p->num_genomes - 1] = ~0ULL;
+  return KC_OK;
+}
+
+extern "C" int kc_synth_reads_host(const kc_synth_params *p, uint64_t first_read, uint64_t nreads, uint8_t *bases, uint8_t *quals,
+                                   uint64_t *offsets) {
+  kc_synth_table *t = new (std::nothrow) kc_synth_table;
+  if (!t) return KC_ERR_OUT_OF_MEMORY;
+  int rc = build_synth_table(p, t);
+  if (rc) {
+    delete t;
+    return rc;
+  }
+  const uint32_t L = t->read_len;
+  for (uint64_t r = 0; r < nreads; r++) {
+    uint64_t rstate, start;
+    uint32_t g;
+    bool rev;
+    kc_synth_read_header(t, first_read + r, &rstate, &g, &start, &rev);
+    for (uint32_t i = 0; i < L; i++) kc_synth_base(t, rstate, g, start, rev, i, &bases[r * L + i], &quals[r * L + i]);
+    offsets[r] = r * L;
+  }
+  offsets[nreads] = nreads * L;
+  delete t;
+  return KC_OK;
+}
+
+extern "C" int kc_synth_reads_device(kc_ctx *c, const kc_synth_params *p, uint64_t first_read, uint64_t nreads, uint8_t *d_bases,
+                                     uint8_t *d_quals, uint64_t *d_offsets) {
+  if (!c || !d_bases || !d_quals || !d_offsets) return KC_ERR_INVALID_ARG;
+  HIPCHK(hipSetDevice(c->cfg.device));
+  kc_synth_table *t = new (std::nothrow) kc_synth_table;
+  if (!t) return KC_ERR_OUT_OF_MEMORY;
+  int rc = build_synth_table(p, t);
+  if (rc) {
+    delete t;
+    return rc;
+  }
+  if (!c->d_synth) {
+    hipError_t e = hipMalloc((void **)&c->d_synth, sizeof(kc_synth_table));
+    if (e != hipSuccess) {
+      delete t;
+      return hip_fail(e, "hipMalloc(synth table)", __LINE__);
+    }
+  }
+  hipError_t e = hipMemcpy(c->d_synth, t, sizeof(kc_synth_table), hipMemcpyHostToDevice);
+  delete t;
+  if (e != hipSuccess) return hip_fail(e, "hipMemcpy(synth table)", __LINE__);
+  const uint64_t nquads = nreads * ((p->read_len + 3) / 4);
+  unsigned nblk = (unsigned)std::min<uint64_t>((nquads + 255) / 256, 256 * 64);
+  if (!nblk) nblk = 1;
+  hipLaunchKernelGGL(kc_synth_kernel, dim3(nblk), dim3(256), 0, c->stream, c->d_synth, first_read, nreads, d_bases, d_quals, d_offsets);
+  HIPCHK(hipGetLastError());
+  HIPCHK(hipStreamSynchronize(c->stream));
+  return KC_OK;
+}

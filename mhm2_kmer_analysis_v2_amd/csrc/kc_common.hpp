@@ -1,0 +1,184 @@
+// kc_common.hpp -- arithmetic shared by host and device code of libkcount_mi355:
+// 2-bit k-mer words, reverse complement, the shard/slot hash, the synthetic read
+// stream.  Compiled by hipcc for both sides (KC_HD).
+//
+// Layout of a k-mer (same as the reference's Kmer<MAX_K>, src/kmer.cpp:228-236,255):
+// base j sits in bits [63-2(j%32)-1 .. 63-2(j%32)] of word j/32, A0 C1 G2 T3,
+// unused trailing bits zero, num_longs = k/32+1 words (src/main.cpp:169-190).
+#pragma once
+#include <stdint.h>
+
+#if defined(__HIPCC__)
+#include <hip/hip_runtime.h>
+#define KC_HD __host__ __device__ __forceinline__
+#else
+#define KC_HD static inline
+#endif
+
+#define KC_MAX_LONGS 4
+#define KC_QUAL_CUTOFF 20   // KCOUNT_QUAL_CUTOFF, CMakeDefinitions.txt:58
+#define KC_EXT_NONE 4u      // extension code for '0' / 'N' (ignored by ExtCounts::inc, kcount_cpu.cpp:157-164)
+#define KC_EXT_BITS 6
+#define KC_EXT_MASK 0x3FULL
+#define KC_COUNT_MAX 65535u // kmer_count_t = uint16_t, kmer_dht.hpp:54
+
+// S3: A0 C1 G2 T3, N (0x4E) -> 2, case-insensitive.  Same truth table as
+// x=(c&4)>>1; x+((x^(c&2))>>1) of src/kmer.cpp:191-192.
+KC_HD uint32_t kc_base_code(uint32_t c) {
+  uint32_t b = (c >> 1) & 3u;
+  return b ^ (b >> 1);
+}
+
+KC_HD bool kc_is_acgt(uint32_t c) {
+  uint32_t u = c & 0xDFu;  // upper-case
+  return u == 'A' || u == 'C' || u == 'G' || u == 'T';
+}
+
+KC_HD bool kc_is_base_char(uint32_t c) {
+  uint32_t u = c & 0xDFu;
+  return u == 'A' || u == 'C' || u == 'G' || u == 'T' || u == 'N';
+}
+
+// reverse the 32 2-bit groups of a word and complement them
+KC_HD uint64_t kc_rc_word(uint64_t v) {
+#if defined(__HIP_DEVICE_COMPILE__)
+  v = __brevll(v);
+  v = ((v >> 1) & 0x5555555555555555ULL) | ((v & 0x5555555555555555ULL) << 1);
+#else
+  v = ((v >> 2) & 0x3333333333333333ULL) | ((v & 0x3333333333333333ULL) << 2);
+  v = ((v >> 4) & 0x0F0F0F0F0F0F0F0FULL) | ((v & 0x0F0F0F0F0F0F0F0FULL) << 4);
+  v = __builtin_bswap64(v);
+#endif
+  return ~v;
+}
+
+// mask keeping the bases of word j of a k-mer
+KC_HD uint64_t kc_word_mask(int k, int j) {
+  int nb = k - 32 * j;
+  if (nb >= 32) return ~0ULL;
+  if (nb <= 0) return 0ULL;
+  return ~(~0ULL >> (2 * nb));
+}
+
+// S4 helper: reverse complement of a packed k-mer (src/kmer.cpp:490-510)
+template <int NL>
+KC_HD void kc_revcomp(const uint64_t (&w)[NL], int k, uint64_t (&out)[NL]) {
+  const int ll = (k + 31) / 32;  // words that hold bases
+  uint64_t t[NL];
+#pragma unroll
+  for (int j = 0; j < NL; j++) t[j] = 0;
+#pragma unroll
+  for (int j = 0; j < NL; j++)
+    if (j < ll) t[ll - 1 - j] = kc_rc_word(w[j]);
+  const int sh = 64 * ll - 2 * k;  // 0..62
+  if (sh) {
+#pragma unroll
+    for (int j = 0; j < NL; j++) {
+      uint64_t nxt = (j + 1 < NL) ? t[j + 1] : 0ULL;
+      t[j] = (t[j] << sh) | (nxt >> (64 - sh));
+    }
+  }
+#pragma unroll
+  for (int j = 0; j < NL; j++) out[j] = (j < ll) ? t[j] : 0ULL;
+}
+
+template <int NL>
+KC_HD bool kc_less(const uint64_t (&a)[NL], const uint64_t (&b)[NL]) {
+#pragma unroll
+  for (int j = 0; j < NL; j++) {
+    if (a[j] < b[j]) return true;
+    if (a[j] > b[j]) return false;
+  }
+  return false;
+}
+
+KC_HD uint64_t kc_mix64(uint64_t x) {
+  x ^= x >> 33;
+  x *= 0xff51afd7ed558ccdULL;
+  x ^= x >> 33;
+  x *= 0xc4ceb9fe1a85ec53ULL;
+  x ^= x >> 33;
+  return x;
+}
+
+// 64-bit hash of a canonical k-mer (extension bits already cleared).  The high 32
+// bits pick the owner shard, the low bits the table slot, so the two are
+// independent.  Any deterministic function gives the same final set (F3).
+template <int NL>
+KC_HD uint64_t kc_hash(const uint64_t (&key)[NL]) {
+  uint64_t h = 0x9E3779B97F4A7C15ULL;
+#pragma unroll
+  for (int j = 0; j < NL; j++) h = kc_mix64(h ^ key[j]);
+  return h;
+}
+
+KC_HD uint32_t kc_owner_of_hash(uint64_t h, uint32_t rank_n) {
+  return (uint32_t)(((h >> 32) * (uint64_t)rank_n) >> 32);
+}
+
+// ---- synthetic read stream ---------------------------------
+#define KC_SYNTH_MAX_GENOMES 1024
+
+struct kc_synth_table {
+  uint64_t seed;
+  uint32_t num_genomes;
+  uint32_t read_len;
+  uint64_t err_thr;   // thresholds on a 64-bit uniform
+  uint64_t lowq_thr;  // err + lowq
+  uint64_t n_thr;
+  uint64_t genome_len[KC_SYNTH_MAX_GENOMES];
+  uint64_t genome_seed[KC_SYNTH_MAX_GENOMES];
+  uint64_t cum[KC_SYNTH_MAX_GENOMES];  // cumulative sampling weight scaled to 2^64-1
+};
+
+KC_HD uint64_t kc_splitmix(uint64_t x) {
+  x += 0x9E3779B97F4A7C15ULL;
+  x = (x ^ (x >> 30)) * 0xBF58476D1CE4E5B9ULL;
+  x = (x ^ (x >> 27)) * 0x94D049BB133111EBULL;
+  return x ^ (x >> 31);
+}
+
+KC_HD uint32_t kc_genome_base(uint64_t gseed, uint64_t pos) { return (uint32_t)(kc_splitmix(gseed + pos * 0xD1342543DE82EF95ULL) >> 62); }
+
+// one base + quality of read r at offset i
+KC_HD void kc_synth_base(const kc_synth_table *t, uint64_t rstate, uint32_t g, uint64_t start, bool rev, uint32_t i,
+                         uint8_t *base, uint8_t *qual) {
+  const uint32_t L = t->read_len;
+  uint64_t pos = rev ? start + (L - 1 - i) : start + i;
+  uint32_t b = kc_genome_base(t->genome_seed[g], pos);
+  if (rev) b = 3u - b;
+  uint64_t u = kc_splitmix(rstate + 0x632BE59BD9B4E019ULL * (uint64_t)(i + 1));
+  uint8_t q = 'I';
+  if (u < t->err_thr) {
+    b = (b + 1u + (uint32_t)((u >> 7) % 3u)) & 3u;
+    q = '#';
+  } else if (u < t->lowq_thr) {
+    q = '#';
+  }
+  uint8_t c = (uint8_t)("ACGT"[b]);
+  if (t->n_thr) {
+    uint64_t u2 = kc_splitmix(u ^ 0xA5A5A5A5A5A5A5A5ULL);
+    if (u2 < t->n_thr) {
+      c = 'N';
+      q = '#';
+    }
+  }
+  *base = c;
+  *qual = q;
+}
+
+KC_HD void kc_synth_read_header(const kc_synth_table *t, uint64_t r, uint64_t *rstate, uint32_t *g, uint64_t *start,
+                                bool *rev) {
+  uint64_t s = kc_splitmix(t->seed ^ (r * 0x9E3779B97F4A7C15ULL));
+  uint64_t u1 = kc_splitmix(s + 1), u2 = kc_splitmix(s + 2), u3 = kc_splitmix(s + 3);
+  uint32_t lo = 0, hi = t->num_genomes - 1;
+  while (lo < hi) {
+    uint32_t mid = (lo + hi) >> 1;
+    if (u1 <= t->cum[mid]) hi = mid; else lo = mid + 1;
+  }
+  *g = lo;
+  uint64_t span = t->genome_len[lo] - t->read_len + 1;
+  *start = u2 % span;
+  *rev = (u3 >> 63) != 0;
+  *rstate = s;
+}

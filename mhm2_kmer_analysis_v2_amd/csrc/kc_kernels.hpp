@@ -1,0 +1,530 @@
+// kc_kernels.hpp -- gfx950 kernels of libkcount_mi355 (wave64, no MFMA: integer / hash work).
+//
+//   kc_extract_kernel      reads -> canonical k-mer records (+ packed extension codes), then either
+//                          inserts them into this shard's table or bins them by owner shard.
+//                          Replaces parse_and_pack / build_supermers / pack_seqs and
+//                          gpu_unpack_supermer_block / get_kmer_from_supermer of the reference
+//                          (src/kcount/kcount-gpu/parse_and_pack.cpp:127-237,
+//                          gpu_hash_table.cpp:281-355) with the CPU backend's semantics (S1-S5).
+//   kc_insert_records_kernel  records -> table (receiver side; gpu_insert_kmer's role,
+//                          gpu_hash_table.cpp:357-424, with S6 saturation instead of the GPU variant's).
+//   kc_finalize_kernel     S7 vote + S8 purge + dense compaction (replaces gpu_purge_invalid +
+//                          gpu_compact_ht + the host loop of kcount_gpu.cpp:438-471).
+//
+// A tile is TILE consecutive base positions of the concatenated read array.  Each workgroup stages
+// its tile once in LDS as 2-bit codes (32 bases per u64 word), an "extension usable" bit per base and
+// a "read boundary" bit per gap; every k-mer is then cut out of the packed words with one funnel
+// shift per word instead of being re-packed from k ASCII bytes per thread.
+#pragma once
+#include "kc_common.hpp"
+
+namespace kc {
+
+constexpr int TPB = 256;
+constexpr int PPT = 16;                 // positions per thread
+constexpr int TILE = TPB * PPT;         // 4096 positions per workgroup
+constexpr int PRE = 32;                 // staged positions before the tile (left neighbour of its first k-mer)
+constexpr int POST = 192;               // staged positions after it: k+1 <= 128, + one word for the funnel, + slack
+constexpr int LSPAN = PRE + TILE + POST;  // 4320
+constexpr int NGROUP = LSPAN / 16;      // 270 sixteen-base groups
+constexpr int NWORD = LSPAN / 32;       // 135
+
+constexpr uint64_t KEY_EMPTY = ~0ULL;
+constexpr uint64_t KEY_BUSY = ~0ULL - 1;
+
+enum { MODE_INSERT = 0, MODE_BIN = 1 };
+enum { FMT_READS = 0, FMT_SEQBLOCK = 1 };
+
+// device-side counters, one u64 each (host mirror in kc_api)
+enum {
+  CTR_ENTRIES = 0,   // occupied table slots
+  CTR_INSERTED,      // k-mer occurrences inserted
+  CTR_BAD_BASE,      // != 0: a byte outside the alphabet was seen
+  CTR_OUT,           // finalize: results written
+  CTR_PURGED,
+  CTR_SUM_COUNTS,
+  CTR_RAW_KMERS,
+  CTR_OVERFLOW,      // bin mode: a segment was too small
+  CTR_BIN0,          // [CTR_BIN0 + d]: records binned for shard d (64 slots)
+  CTR_COUNT = CTR_BIN0 + 64
+};
+
+struct Table {
+  uint64_t *keys;   // capacity * NL words, 0xFF-filled when empty
+  uint32_t *vals;   // capacity * 9: count, left ACGT, right ACGT (clipped to 65535 when read out: S6)
+  uint64_t mask;    // capacity - 1 (capacity is a power of two)
+};
+
+struct ExtractArgs {
+  const uint8_t *bases;     // 16-byte aligned base address (bases - align)
+  const uint8_t *quals;     // same shift applied; only FMT_READS
+  const uint64_t *offsets;  // nreads+1, relative to the first real byte; only FMT_READS
+  const uint64_t *tile_first;  // per tile: first read whose start is at or after the tile's first position
+  uint64_t nreads;
+  uint64_t total;           // bytes of real data
+  uint32_t align;           // real data starts at aligned coordinate `align` (0..15)
+  uint32_t quals_vector_ok; // quals can be loaded 16 bytes at a time at the same shift
+  uint64_t tile0;           // first tile of this launch
+  int k;
+  int qual_cut;             // qual_offset + KC_QUAL_CUTOFF
+  uint32_t rank_me, rank_n;
+  // MODE_BIN
+  uint64_t *records;
+  uint64_t seg_capacity;
+};
+
+__device__ __forceinline__ uint32_t lane_id() { return __lane_id(); }
+
+// ---- table ------------------------------------------------------------------------------
+__device__ __forceinline__ void sat_inc(uint32_t *p) {
+  uint32_t old = atomicAdd(p, 1u);
+  if (old >= 0x80000000u) atomicSub(p, 1u);  // far above 65535 already; keeps the u32 from wrapping
+}
+
+// Insert one record (canonical k-mer + extension codes).  Linear probing, power-of-two capacity;
+// the host keeps the load below 0.9 by growing the table, so the probe always terminates and
+// nothing is ever dropped (the reference drops after KCOUNT_HT_MAX_PROBE, kcount_cpu.cpp:232-268).
+template <int NL>
+__device__ __forceinline__ void table_insert(const Table &t, const uint64_t (&rec)[NL], uint64_t *ctrs) {
+  uint64_t key[NL];
+#pragma unroll
+  for (int j = 0; j < NL; j++) key[j] = rec[j];
+  const uint32_t le = (uint32_t)(rec[NL - 1] & 7u), re = (uint32_t)((rec[NL - 1] >> 3) & 7u);
+  key[NL - 1] &= ~KC_EXT_MASK;
+  uint64_t slot = kc_hash<NL>(key) & t.mask;
+  bool is_new = false;
+  if constexpr (NL == 1) {
+    for (;;) {
+      // plain load as a hint: a slot only ever goes EMPTY -> key, so a stale line can only claim
+      // EMPTY, and then the CAS below tells the truth
+      uint64_t cur = t.keys[slot];
+      if (cur == key[0]) break;
+      if (cur == KEY_EMPTY) {
+        uint64_t old = atomicCAS((unsigned long long *)&t.keys[slot], (unsigned long long)KEY_EMPTY,
+                                 (unsigned long long)key[0]);
+        if (old == KEY_EMPTY) { is_new = true; break; }
+        if (old == key[0]) break;
+      }
+      slot = (slot + 1) & t.mask;
+    }
+  } else {
+    // the last word is lock + publish: EMPTY -> BUSY -> value.  Every read of shared key words is a
+    // device-scope RMW so that it is served by the coherent memory side, never by another XCD's L2.
+    for (;;) {
+      unsigned long long *ks = (unsigned long long *)(t.keys + slot * NL);
+      uint64_t old = atomicCAS(&ks[NL - 1], (unsigned long long)KEY_EMPTY, (unsigned long long)KEY_BUSY);
+      if (old == KEY_EMPTY) {
+#pragma unroll
+        for (int j = 0; j < NL - 1; j++)
+          __hip_atomic_store(&ks[j], (unsigned long long)key[j], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        // the word stores must be performed before the publish below; inline asm is not reordered or dropped
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        atomicExch(&ks[NL - 1], (unsigned long long)key[NL - 1]);
+        is_new = true;
+        break;
+      }
+      if (old == KEY_BUSY) continue;  // owner publishes within this same loop trip of its wave
+      if (old == key[NL - 1]) {
+        bool same = true;
+#pragma unroll
+        for (int j = 0; j < NL - 1; j++) same &= (atomicOr(&ks[j], 0ULL) == key[j]);
+        if (same) break;
+      }
+      slot = (slot + 1) & t.mask;
+    }
+  }
+  uint32_t *v = t.vals + slot * 9;
+  sat_inc(v);                              // S6 count
+  if (le < 4u) sat_inc(v + 1 + le);        // S5/S6 only ACGT extensions are counted
+  if (re < 4u) sat_inc(v + 5 + re);
+  if (is_new) atomicAdd((unsigned long long *)&ctrs[CTR_ENTRIES], 1ULL);
+}
+
+// ---- tile staging --------------------------------------------------------------------------
+struct alignas(16) TileLDS {
+  uint32_t codes[NGROUP];   // 2-bit codes; u64 word w = {codes[2w+1] (first 16 bases), codes[2w]}
+  uint16_t ok[NGROUP];      // bit i: base 16g+i may serve as an extension (high quality, ACGT)
+  uint32_t gap[NWORD + 1];  // bit lp: a read boundary lies between local positions lp-1 and lp
+};
+
+__device__ __forceinline__ uint32_t pack4(uint32_t v) {  // 4 ASCII bytes -> 4 codes, first byte highest
+  uint32_t b = (v >> 1) & 0x03030303u;
+  uint32_t c = b ^ ((b >> 1) & 0x01010101u);
+  return (c * 0x40100401u) >> 24;
+}
+
+constexpr uint32_t BM_ACGT = (1u << 1) | (1u << 3) | (1u << 7) | (1u << 20);
+constexpr uint32_t BM_ACGTN = BM_ACGT | (1u << 14);
+__device__ __forceinline__ bool in_bitmap(uint32_t c, uint32_t bm) { return ((c & 0xC0u) == 0x40u) && ((bm >> (c & 31u)) & 1u); }
+
+// Stage the tile.  Aligned coordinate x = byte index from the 16-byte aligned base address; local
+// position lp = x - (T0 - PRE).
+template <int FMT>
+__device__ __forceinline__ void stage_tile(TileLDS &L, const ExtractArgs &a, int64_t T0, uint64_t *ctrs) {
+  const int tid = threadIdx.x;
+  for (int i = tid; i < NWORD + 1; i += TPB) L.gap[i] = 0;
+  __syncthreads();
+  const int64_t lo = a.align, hi = (int64_t)a.align + (int64_t)a.total;  // real data is [lo, hi)
+  bool bad = false;
+  for (int g = tid; g < NGROUP; g += TPB) {
+    const int64_t X0 = T0 - PRE + 16 * g;
+    uint32_t bw[4] = {0, 0, 0, 0}, qw[4] = {0, 0, 0, 0};
+    const bool any = (X0 + 16 > lo) && (X0 < hi);
+    const bool full = (X0 >= lo) && (X0 + 16 <= hi);
+    if (any) {
+      // the 16-byte line holding the group is inside the allocation's aligned span whenever any
+      // of its bytes is real data, so the vector load is safe; bytes outside [lo,hi) are masked below
+      uint4 v = *reinterpret_cast<const uint4 *>(a.bases + X0);
+      bw[0] = v.x; bw[1] = v.y; bw[2] = v.z; bw[3] = v.w;
+      if (FMT == FMT_READS) {
+        if (a.quals_vector_ok) {
+          uint4 q = *reinterpret_cast<const uint4 *>(a.quals + X0);
+          qw[0] = q.x; qw[1] = q.y; qw[2] = q.z; qw[3] = q.w;
+        } else {
+          for (int i = 0; i < 16; i++) {
+            int64_t x = X0 + i;
+            if (x >= lo && x < hi) qw[i >> 2] |= (uint32_t)a.quals[x] << (8 * (i & 3));
+          }
+        }
+      }
+    }
+    uint32_t code = (pack4(bw[0]) << 24) | (pack4(bw[1]) << 16) | (pack4(bw[2]) << 8) | pack4(bw[3]);
+    uint32_t okm = 0, sepm = 0;
+#pragma unroll
+    for (int i = 0; i < 16; i++) {
+      const uint32_t c = (bw[i >> 2] >> (8 * (i & 3))) & 0xFFu;
+      const bool real = full || (any && (X0 + i >= lo) && (X0 + i < hi));
+      bool hq;
+      if (FMT == FMT_READS) {
+        const int q = (int)((qw[i >> 2] >> (8 * (i & 3))) & 0xFFu);
+        hq = q >= a.qual_cut;                                 // S2
+        if (real && !in_bitmap(c, BM_ACGTN)) bad = true;
+      } else {
+        hq = (c & 0x20u) == 0;                                // case carries the quality
+        const bool sep = (c == '_');
+        if (real && sep) sepm |= 1u << i;
+        if (real && !sep && !in_bitmap(c, BM_ACGTN)) bad = true;
+      }
+      if (real && hq && in_bitmap(c, BM_ACGT)) okm |= 1u << i;
+    }
+    L.codes[g ^ 1] = code;
+    L.ok[g] = (uint16_t)okm;
+    if (FMT == FMT_SEQBLOCK && sepm) {
+      // a separator at q kills every window [p-1, p+k] that contains q: gaps q and q+1
+      uint64_t bits = ((uint64_t)sepm | ((uint64_t)sepm << 1)) << (16 * (g & 1));
+      atomicOr(&L.gap[g >> 1], (uint32_t)bits);
+      if (bits >> 32) atomicOr(&L.gap[(g >> 1) + 1], (uint32_t)(bits >> 32));
+    }
+  }
+  if (FMT == FMT_READS) {
+    // boundaries from the read offsets (the end of the data is offsets[nreads])
+    const int64_t first = T0, last = T0 + TILE + a.k;  // gaps that any window of this tile can contain
+    for (uint64_t r = a.tile_first[blockIdx.x] + tid; r <= a.nreads; r += TPB) {
+      int64_t s = (int64_t)a.offsets[r] + lo;
+      if (s > last) break;
+      if (s >= first) {
+        int lp = (int)(s - (T0 - PRE));
+        atomicOr(&L.gap[lp >> 5], 1u << (lp & 31));
+      }
+    }
+  } else {
+    // start and end of the block are boundaries too
+    if (tid == 0) {
+      int64_t s0 = lo - (T0 - PRE), s1 = hi - (T0 - PRE);
+      if (s0 >= 0 && s0 < LSPAN) atomicOr(&L.gap[s0 >> 5], 1u << (s0 & 31));
+      if (s1 >= 0 && s1 < LSPAN) atomicOr(&L.gap[s1 >> 5], 1u << (s1 & 31));
+    }
+  }
+  if (bad) ctrs[CTR_BAD_BASE] = 1;
+  __syncthreads();
+}
+
+// Cut the k-mer that starts at local position lp out of the staged tile.  Returns false if the
+// window [lp-1, lp+k] crosses a read boundary (S1, S5).  rec = canonical k-mer (S3, S4) with the
+// extension codes (S5) in the low 6 bits of its last word; h = hash of the bare k-mer.
+template <int NL>
+__device__ __forceinline__ bool tile_kmer(const TileLDS &L, int lp, int k, uint64_t (&rec)[NL], uint64_t &h) {
+  {  // any boundary among gaps lp .. lp+k ?
+    int rem = k + 1, w = lp >> 5, s = lp & 31;
+    uint32_t badbits = L.gap[w] >> s;
+    int got = 32 - s;
+    if (got >= rem) {
+      if (rem < 32) badbits &= (1u << rem) - 1u;
+    } else {
+      rem -= got;
+      w++;
+      while (rem >= 32) { badbits |= L.gap[w++]; rem -= 32; }
+      if (rem) badbits |= L.gap[w] & ((1u << rem) - 1u);
+    }
+    if (badbits) return false;
+  }
+  const uint64_t *W = reinterpret_cast<const uint64_t *>(L.codes);
+  const int q = lp >> 5, sh = 2 * (lp & 31);
+  uint64_t f[NL], r[NL];
+#pragma unroll
+  for (int j = 0; j < NL; j++) {
+    uint64_t hi = W[q + j], lo = W[q + j + 1];
+    f[j] = (sh ? ((hi << sh) | (lo >> (64 - sh))) : hi) & kc_word_mask(k, j);
+  }
+  kc_revcomp<NL>(f, k, r);
+  // extension codes of the two neighbours
+  const int pl = lp - 1, pr = lp + k;
+  uint32_t lc = (uint32_t)(W[pl >> 5] >> (62 - 2 * (pl & 31))) & 3u;
+  uint32_t rc = (uint32_t)(W[pr >> 5] >> (62 - 2 * (pr & 31))) & 3u;
+  uint32_t le = ((L.ok[pl >> 4] >> (pl & 15)) & 1u) ? lc : KC_EXT_NONE;
+  uint32_t re = ((L.ok[pr >> 4] >> (pr & 15)) & 1u) ? rc : KC_EXT_NONE;
+  if (kc_less<NL>(r, f)) {  // strict: a palindrome keeps the forward extensions
+#pragma unroll
+    for (int j = 0; j < NL; j++) f[j] = r[j];
+    uint32_t nl = (re == KC_EXT_NONE) ? KC_EXT_NONE : 3u - re;
+    uint32_t nr = (le == KC_EXT_NONE) ? KC_EXT_NONE : 3u - le;
+    le = nl;
+    re = nr;
+  }
+  h = kc_hash<NL>(f);
+#pragma unroll
+  for (int j = 0; j < NL; j++) rec[j] = f[j];
+  rec[NL - 1] |= (uint64_t)(le | (re << 3));
+  return true;
+}
+
+template <int NL, int MODE, int FMT>
+__global__ __launch_bounds__(TPB) void kc_extract_kernel(ExtractArgs a, Table t, uint64_t *ctrs) {
+  __shared__ TileLDS L;
+  const int64_t T0 = (int64_t)(a.tile0 + blockIdx.x) * TILE;
+  stage_tile<FMT>(L, a, T0, ctrs);
+  const int64_t lo = a.align, hi = (int64_t)a.align + (int64_t)a.total;
+  uint32_t n_ins = 0;
+#pragma unroll 1
+  for (int it = 0; it < PPT; it++) {
+    const int off = it * TPB + threadIdx.x;
+    const int64_t x = T0 + off;
+    uint64_t rec[NL], h = 0;
+    bool valid = (x > lo) && (x + a.k < hi) && tile_kmer<NL>(L, PRE + off, a.k, rec, h);
+    uint32_t owner = 0;
+    if (valid && a.rank_n > 1) owner = kc_owner_of_hash(h, a.rank_n);
+    if (MODE == MODE_INSERT) {
+      if (valid && owner == a.rank_me) {
+        table_insert<NL>(t, rec, ctrs);
+        n_ins++;
+      }
+    } else {
+      // bin by owner shard: one cursor bump per wave and shard present
+      for (uint32_t d = 0; d < a.rank_n; d++) {
+        const bool mine = valid && owner == d;
+        const uint64_t m = __ballot(mine);
+        if (!m) continue;
+        const uint32_t cnt = (uint32_t)__popcll(m);
+        uint64_t base = 0;
+        if (lane_id() == (uint32_t)__ffsll((long long)m) - 1)
+          base = atomicAdd((unsigned long long *)&ctrs[CTR_BIN0 + d], (unsigned long long)cnt);
+        base = __shfl(base, __ffsll((long long)m) - 1);
+        if (mine) {
+          const uint64_t idx = base + (uint64_t)__popcll(m & ((1ULL << lane_id()) - 1ULL));
+          if (idx < a.seg_capacity) {
+            uint64_t *dst = a.records + ((uint64_t)d * a.seg_capacity + idx) * NL;
+#pragma unroll
+            for (int j = 0; j < NL; j++) dst[j] = rec[j];
+          } else {
+            ctrs[CTR_OVERFLOW] = 1;
+          }
+        }
+      }
+    }
+  }
+  if (MODE == MODE_INSERT) {
+    // wave-reduce then one atomic
+    for (int o = 32; o > 0; o >>= 1) n_ins += __shfl_down(n_ins, o);
+    if (lane_id() == 0 && n_ins) atomicAdd((unsigned long long *)&ctrs[CTR_INSERTED], (unsigned long long)n_ins);
+  }
+}
+
+template <int NL>
+__global__ __launch_bounds__(TPB) void kc_insert_records_kernel(const uint64_t *recs, uint64_t n, Table t, uint64_t *ctrs) {
+  const uint64_t stride = (uint64_t)gridDim.x * TPB;
+  uint32_t n_ins = 0;
+  for (uint64_t i = (uint64_t)blockIdx.x * TPB + threadIdx.x; i < n; i += stride) {
+    uint64_t rec[NL];
+#pragma unroll
+    for (int j = 0; j < NL; j++) rec[j] = recs[i * NL + j];
+    table_insert<NL>(t, rec, ctrs);
+    n_ins++;
+  }
+  for (int o = 32; o > 0; o >>= 1) n_ins += __shfl_down(n_ins, o);
+  if (lane_id() == 0 && n_ins) atomicAdd((unsigned long long *)&ctrs[CTR_INSERTED], (unsigned long long)n_ins);
+}
+
+// first read whose start lies at or after each tile's first position (lower bound on the offsets)
+__global__ void kc_tile_first_kernel(const uint64_t *offsets, uint64_t nreads, uint32_t align, uint64_t tile0, uint64_t ntiles,
+                                     uint64_t *tile_first) {
+  uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= ntiles) return;
+  int64_t T0 = (int64_t)(tile0 + i) * TILE - (int64_t)align;  // in offset coordinates
+  uint64_t lo = 0, hi = nreads + 1;                            // offsets has nreads+1 entries
+  while (lo < hi) {
+    uint64_t mid = (lo + hi) >> 1;
+    if ((int64_t)offsets[mid] < T0) lo = mid + 1; else hi = mid;
+  }
+  tile_first[i] = lo;
+}
+
+// raw k-mers of the block: sum over reads of max(0, len-k+1) (kcount.cpp:78,86)
+__global__ void kc_read_stats_kernel(const uint64_t *offsets, uint64_t nreads, int k, uint64_t *ctrs) {
+  uint64_t acc = 0;
+  const uint64_t stride = (uint64_t)gridDim.x * blockDim.x;
+  for (uint64_t r = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x; r < nreads; r += stride) {
+    uint64_t len = offsets[r + 1] - offsets[r];
+    if (len >= (uint64_t)k) acc += len - k + 1;
+  }
+  for (int o = 32; o > 0; o >>= 1) acc += __shfl_down(acc, o);
+  if (lane_id() == 0 && acc) atomicAdd((unsigned long long *)&ctrs[CTR_RAW_KMERS], (unsigned long long)acc);
+}
+
+// the same for a '_'-joined block: count runs of non-separator bytes
+__global__ void kc_seqblock_stats_kernel(const uint8_t *seqs, uint64_t len, int k, uint64_t *ctrs) {
+  // one thread per byte that ends a run (next byte is '_' or end): walks back to the run start
+  uint64_t acc = 0;
+  const uint64_t stride = (uint64_t)gridDim.x * blockDim.x;
+  for (uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x; i < len; i += stride) {
+    if (seqs[i] == '_') continue;
+    if (i + 1 < len && seqs[i + 1] != '_') continue;
+    uint64_t j = i;
+    while (j > 0 && seqs[j - 1] != '_') j--;
+    uint64_t rl = i - j + 1;
+    if (rl >= (uint64_t)k) acc += rl - k + 1;
+  }
+  for (int o = 32; o > 0; o >>= 1) acc += __shfl_down(acc, o);
+  if (lane_id() == 0 && acc) atomicAdd((unsigned long long *)&ctrs[CTR_RAW_KMERS], (unsigned long long)acc);
+}
+
+// ---- finalize ----------------------------------------------------------------------------------
+// S7: ExtCounts::get_ext (kcount_cpu.cpp:135-145,173-182).  Returns 0-3 = ACGT, 4 = 'X', 5 = 'F'.
+__device__ __forceinline__ uint32_t vote_ext(const uint32_t (&c)[4], uint32_t count, int dmin_thres) {
+  uint32_t top = 0;
+#pragma unroll
+  for (uint32_t i = 1; i < 4; i++)
+    if (c[i] >= c[top]) top = i;  // ties go to the later letter
+  uint32_t runner = 0;
+#pragma unroll
+  for (uint32_t i = 0; i < 4; i++)
+    if (i != top && c[i] > runner) runner = c[i];
+  // the reference's expression, in double, truncated toward zero: (int)((1.0 - DYN_MIN_DEPTH) * count)
+  int dmin_dyn = (int)((1.0 - 0.9) * (double)count);
+  if (dmin_dyn < dmin_thres) dmin_dyn = dmin_thres;
+  if ((int)c[top] < dmin_dyn) return 4u;
+  if ((int)runner >= dmin_dyn) return 5u;
+  return top;
+}
+
+template <int NL>
+__global__ __launch_bounds__(TPB) void kc_finalize_kernel(Table t, uint64_t capacity, int dmin_thres, uint64_t *out_keys,
+                                                           uint16_t *out_counts, uint8_t *out_left, uint8_t *out_right,
+                                                           uint64_t *ctrs) {
+  const uint64_t stride = (uint64_t)gridDim.x * TPB;
+  uint64_t purged = 0, sum = 0;
+  const uint64_t nround = (capacity + stride - 1) / stride;
+  for (uint64_t rnd = 0; rnd < nround; rnd++) {
+    const uint64_t s = rnd * stride + (uint64_t)blockIdx.x * TPB + threadIdx.x;
+    bool keep = false;
+    uint32_t count = 0, l = 0, r = 0;
+    if (s < capacity && t.keys[s * NL + NL - 1] != KEY_EMPTY) {
+      const uint32_t *v = t.vals + s * 9;
+      count = min(v[0], KC_COUNT_MAX);
+      uint32_t lc[4], rc[4];
+#pragma unroll
+      for (int i = 0; i < 4; i++) {
+        lc[i] = min(v[1 + i], KC_COUNT_MAX);
+        rc[i] = min(v[5 + i], KC_COUNT_MAX);
+      }
+      if (count >= 2) {  // S8
+        l = vote_ext(lc, count, dmin_thres);
+        r = vote_ext(rc, count, dmin_thres);
+        keep = (l < 4u) && (r < 4u);
+      }
+      if (!keep) purged++;
+    }
+    const uint64_t m = __ballot(keep);
+    if (m) {
+      const int leader = __ffsll((long long)m) - 1;
+      uint64_t base = 0;
+      if ((int)lane_id() == leader) base = atomicAdd((unsigned long long *)&ctrs[CTR_OUT], (unsigned long long)__popcll(m));
+      base = __shfl(base, leader);
+      if (keep) {
+        const uint64_t o = base + (uint64_t)__popcll(m & ((1ULL << lane_id()) - 1ULL));
+#pragma unroll
+        for (int j = 0; j < NL; j++) out_keys[o * NL + j] = t.keys[s * NL + j];
+        out_counts[o] = (uint16_t)count;
+        out_left[o] = (uint8_t)("ACGT"[l]);
+        out_right[o] = (uint8_t)("ACGT"[r]);
+        sum += count;
+      }
+    }
+  }
+  for (int o = 32; o > 0; o >>= 1) {
+    purged += __shfl_down(purged, o);
+    sum += __shfl_down(sum, o);
+  }
+  if (lane_id() == 0) {
+    if (purged) atomicAdd((unsigned long long *)&ctrs[CTR_PURGED], (unsigned long long)purged);
+    if (sum) atomicAdd((unsigned long long *)&ctrs[CTR_SUM_COUNTS], (unsigned long long)sum);
+  }
+}
+
+// every entry, unfiltered (tests of S5/S6)
+template <int NL>
+__global__ void kc_dump_kernel(Table t, uint64_t capacity, uint64_t *out_keys, uint16_t *out_counts, uint16_t *out_exts,
+                               uint64_t *cursor) {
+  const uint64_t s = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (s >= capacity || t.keys[s * NL + NL - 1] == KEY_EMPTY) return;
+  const uint64_t o = atomicAdd((unsigned long long *)cursor, 1ULL);
+  for (int j = 0; j < NL; j++) out_keys[o * NL + j] = t.keys[s * NL + j];
+  const uint32_t *v = t.vals + s * 9;
+  out_counts[o] = (uint16_t)min(v[0], KC_COUNT_MAX);
+  for (int i = 0; i < 8; i++) out_exts[o * 8 + i] = (uint16_t)min(v[1 + i], KC_COUNT_MAX);
+}
+
+// move every entry of a full table into a bigger one (keys are unique, so values can be stored plainly)
+template <int NL>
+__global__ void kc_rehash_kernel(Table from, uint64_t from_capacity, Table to) {
+  const uint64_t s = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (s >= from_capacity || from.keys[s * NL + NL - 1] == KEY_EMPTY) return;
+  uint64_t key[NL];
+  for (int j = 0; j < NL; j++) key[j] = from.keys[s * NL + j];
+  uint64_t slot = kc_hash<NL>(key) & to.mask;
+  for (;;) {
+    unsigned long long *ks = (unsigned long long *)(to.keys + slot * NL);
+    if (atomicCAS(&ks[NL - 1], (unsigned long long)KEY_EMPTY, (unsigned long long)key[NL - 1]) == KEY_EMPTY) {
+      for (int j = 0; j < NL - 1; j++) ks[j] = key[j];
+      break;
+    }
+    slot = (slot + 1) & to.mask;
+  }
+  for (int i = 0; i < 9; i++) to.vals[slot * 9 + i] = from.vals[s * 9 + i];
+}
+
+// ---- synthetic reads ----------------------------------------------------------------------------
+__global__ void kc_synth_kernel(const kc_synth_table *tab, uint64_t first_read, uint64_t nreads, uint8_t *bases,
+                                uint8_t *quals, uint64_t *offsets) {
+  const uint32_t L = tab->read_len;
+  const uint64_t stride = (uint64_t)gridDim.x * blockDim.x;
+  // one thread per 4 bases: a read's header (genome, start, strand) is cheap to recompute
+  const uint64_t nquads = nreads * ((L + 3) / 4);
+  for (uint64_t qd = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x; qd < nquads; qd += stride) {
+    const uint64_t r = qd / ((L + 3) / 4);
+    const uint32_t i0 = (uint32_t)(qd % ((L + 3) / 4)) * 4;
+    uint64_t rstate, start;
+    uint32_t g;
+    bool rev;
+    kc_synth_read_header(tab, first_read + r, &rstate, &g, &start, &rev);
+    for (uint32_t i = i0; i < i0 + 4 && i < L; i++) {
+      uint8_t b, q;
+      kc_synth_base(tab, rstate, g, start, rev, i, &b, &q);
+      bases[r * L + i] = b;
+      quals[r * L + i] = q;
+    }
+    if (i0 == 0) offsets[r] = r * L;
+  }
+  if (blockIdx.x == 0 && threadIdx.x == 0) offsets[nreads] = nreads * L;
+}
+
+}  // namespace kc

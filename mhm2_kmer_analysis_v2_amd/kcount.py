@@ -1,0 +1,190 @@
+"""Python host side over the C ABI: mirrors the reference's analyze_kmers flow.
+
+  reference (src/kcount/kcount.cpp:142-161)          here
+  -------------------------------------------        --------------------------------
+  KmerDHT ctor -> HashTableInserter::init             KmerCounter(k, ...)      kc_create
+  count_kmers: per read quality-mask + process_seq    .submit_reads(...)       kc_submit_reads
+  kmer_dht->flush_updates()                           .flush()                 kc_flush
+  kmer_dht->finish_updates()                          .finalize()              kc_finalize
+  local_kmers (KmerMap)                               .results()               kc_copy_results
+  dump_kmers ("KMER count L R", kmer_dht.cpp:284)     .dump_lines()
+"""
+import ctypes as C
+
+import numpy as np
+
+from . import _lib
+from ._lib import check, kc_config, kc_result, kc_stats, kc_synth_params, lib
+
+
+def _ptr(a):
+    """numpy array / torch tensor / int / None -> address, and whether it is device memory."""
+    if a is None:
+        return None, False
+    if isinstance(a, int):
+        return a, True
+    if hasattr(a, "data_ptr"):  # torch tensor
+        return a.data_ptr(), bool(a.is_cuda)
+    return a.ctypes.data, False
+
+
+def synth_params(**kw):
+    p = kc_synth_params()
+    lib().kc_synth_default_params(C.byref(p))
+    for k, v in kw.items():
+        if not hasattr(p, k):
+            raise TypeError("unknown synth parameter %r" % k)
+        setattr(p, k, v)
+    return p
+
+
+def synth_reads_host(nreads, first_read=0, params=None):
+    """Host generator (same bytes as the device generator): bases u8, quals u8, offsets u64."""
+    p = params or synth_params()
+    L = p.read_len
+    bases = np.empty(nreads * L, dtype=np.uint8)
+    quals = np.empty(nreads * L, dtype=np.uint8)
+    offs = np.empty(nreads + 1, dtype=np.uint64)
+    check(lib().kc_synth_reads_host(C.byref(p), first_read, nreads, bases.ctypes.data, quals.ctypes.data, offs.ctypes.data),
+          "kc_synth_reads_host")
+    return bases, quals, offs
+
+
+class KmerCounter:
+    """One shard (one GPU) of the k-mer analysis stage."""
+
+    def __init__(self, kmer_len, qual_offset=33, dmin_thres=2, device=0, rank_me=0, rank_n=1, max_elems=0):
+        L = lib()
+        cfg = kc_config(kmer_len=kmer_len, qual_offset=qual_offset, dmin_thres=dmin_thres, device=device, rank_me=rank_me,
+                        rank_n=rank_n, max_elems=max_elems, flags=0, reserved=0)
+        st = C.c_int(0)
+        self._h = L.kc_create(C.byref(cfg), C.byref(st))
+        if not self._h:
+            raise _lib.KcError(st.value, "kc_create")
+        self.k = kmer_len
+        self.nl = L.kc_num_longs(kmer_len)
+        self.rank_me, self.rank_n = rank_me, rank_n
+
+    def close(self):
+        if getattr(self, "_h", None):
+            lib().kc_destroy(self._h)
+            self._h = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    def __enter__(self):
+        return self
+
+    def __exit__(self, *a):
+        self.close()
+
+    def set_stream(self, stream_handle):
+        check(lib().kc_set_stream(self._h, stream_handle), "kc_set_stream")
+
+    def reset(self, new_kmer_len=0):
+        check(lib().kc_reset(self._h, new_kmer_len), "kc_reset")
+        if new_kmer_len:
+            self.k = new_kmer_len
+            self.nl = lib().kc_num_longs(new_kmer_len)
+
+    def submit_reads(self, bases, quals, offsets, nreads=None):
+        pb, dev = _ptr(bases)
+        pq, _ = _ptr(quals)
+        po, _ = _ptr(offsets)
+        n = (len(offsets) - 1) if nreads is None else nreads
+        check(lib().kc_submit_reads(self._h, pb, pq, po, n, 1 if dev else 0), "kc_submit_reads")
+
+    def submit_seq_block(self, seqs, length=None):
+        if isinstance(seqs, (bytes, bytearray)):
+            buf = np.frombuffer(bytes(seqs), dtype=np.uint8)
+            check(lib().kc_submit_seq_block(self._h, buf.ctypes.data, len(buf), 0), "kc_submit_seq_block")
+            return
+        p, dev = _ptr(seqs)
+        n = len(seqs) if length is None else length
+        check(lib().kc_submit_seq_block(self._h, p, n, 1 if dev else 0), "kc_submit_seq_block")
+
+    def extract_partition(self, bases, quals, offsets, records, seg_capacity, nreads=None):
+        """records: device buffer of rank_n*seg_capacity*num_longs u64.  Returns per-shard counts."""
+        pb, dev = _ptr(bases)
+        pq, _ = _ptr(quals)
+        po, _ = _ptr(offsets)
+        pr, _ = _ptr(records)
+        n = (len(offsets) - 1) if nreads is None else nreads
+        counts = np.zeros(self.rank_n, dtype=np.uint64)
+        check(lib().kc_extract_partition(self._h, pb, pq, po, n, 1 if dev else 0, pr, seg_capacity, counts.ctypes.data),
+              "kc_extract_partition")
+        return counts
+
+    def insert_records(self, records, n):
+        pr, _ = _ptr(records)
+        check(lib().kc_insert_records(self._h, pr, n), "kc_insert_records")
+
+    def flush(self):
+        check(lib().kc_flush(self._h), "kc_flush")
+
+    def finalize(self):
+        r = kc_result()
+        check(lib().kc_finalize(self._h, C.byref(r)), "kc_finalize")
+        self._res = r
+        return r
+
+    def results(self):
+        """Host copies: keys (n, num_longs) u64, counts u16, left u8, right u8 (unordered)."""
+        r = self.finalize()
+        n = int(r.n)
+        keys = np.empty((n, self.nl), dtype=np.uint64)
+        counts = np.empty(n, dtype=np.uint16)
+        left = np.empty(n, dtype=np.uint8)
+        right = np.empty(n, dtype=np.uint8)
+        check(lib().kc_copy_results(self._h, keys.ctypes.data, counts.ctypes.data, left.ctypes.data, right.ctypes.data),
+              "kc_copy_results")
+        return keys, counts, left, right
+
+    def sorted_results(self):
+        keys, counts, left, right = self.results()
+        order = np.lexsort([keys[:, j] for j in range(self.nl - 1, -1, -1)]) if len(counts) else np.zeros(0, dtype=np.int64)
+        return keys[order], counts[order], left[order], right[order]
+
+    def dump_table(self):
+        n = C.c_uint64(0)
+        check(lib().kc_dump_table(self._h, None, None, None, C.byref(n)), "kc_dump_table")
+        keys = np.empty((n.value, self.nl), dtype=np.uint64)
+        counts = np.empty(n.value, dtype=np.uint16)
+        exts = np.empty((n.value, 8), dtype=np.uint16)
+        if n.value:
+            check(lib().kc_dump_table(self._h, keys.ctypes.data, counts.ctypes.data, exts.ctypes.data, C.byref(n)), "kc_dump_table")
+        order = np.lexsort([keys[:, j] for j in range(self.nl - 1, -1, -1)]) if n.value else np.zeros(0, dtype=np.int64)
+        return keys[order], counts[order], exts[order]
+
+    def stats(self):
+        s = kc_stats()
+        check(lib().kc_get_stats(self._h, C.byref(s)), "kc_get_stats")
+        return {n: int(getattr(s, n)) for n, _ in kc_stats._fields_}
+
+    def synth_reads_device(self, d_bases, d_quals, d_offsets, nreads, first_read=0, params=None):
+        p = params or synth_params()
+        check(lib().kc_synth_reads_device(self._h, C.byref(p), first_read, nreads, _ptr(d_bases)[0], _ptr(d_quals)[0],
+                                          _ptr(d_offsets)[0]), "kc_synth_reads_device")
+
+    def dump_lines(self):
+        """The reference's dump format, one "KMER count L R" per k-mer (kmer_dht.cpp:273-297), sorted."""
+        keys, counts, left, right = self.sorted_results()
+        return ["%s %d %s %s" % (kmer_to_string(keys[i], self.k), counts[i], chr(left[i]), chr(right[i]))
+                for i in range(len(counts))]
+
+
+def kmer_to_string(words, k):
+    return "".join("ACGT"[(int(words[i // 32]) >> (2 * (31 - (i % 32)))) & 3] for i in range(k))
+
+
+def analyze_kmers(kmer_len, qual_offset, bases, quals, offsets, dmin_thres=2, device=0, max_elems=0):
+    """analyze_kmers (src/kcount/kcount.cpp:142-161) for one shard: returns sorted results and stats."""
+    with KmerCounter(kmer_len, qual_offset, dmin_thres, device=device, max_elems=max_elems) as kc:
+        kc.submit_reads(bases, quals, offsets)
+        kc.flush()
+        res = kc.sorted_results()
+        return res, kc.stats()

@@ -40,9 +40,10 @@
  * Deliberate differences (none can change results while dropped == 0):
  *   - table capacity is the next prime >= the request, found by trial
  *     division, not looked up in src/kcount/prime.hpp's table;
- *   - a rank's table grows (rehash) when its load passes 0.66 so that the
- *     "no dropped inserts" precondition (kcount_cpu.cpp:266,507-516) holds for
- *     any input; MAX_PROBE=100 drops are still counted if they ever happen;
+ *   - a rank's table grows (rehash) when its load passes 0.66, and also at the
+ *     point where the reference would drop an insert (MAX_PROBE=100 exhausted),
+ *     so that the "no dropped inserts" precondition (kcount_cpu.cpp:266,
+ *     507-516) holds for any input;
  *   - k-mers of a read are produced by a rolling 2-bit window, not the
  *     four-phase shift of kmer.cpp:238-260 (same values).
  */
@@ -346,8 +347,7 @@ static orc_vals *table_insert(orc_table *t, const uint64_t *kmer, int nl) {
     }
     slot = (slot + 1) % t->capacity;
   }
-  t->num_dropped++;
-  return NULL;
+  return NULL; /* no room within MAX_PROBE: the reference counts a drop here (kcount_cpu.cpp:266) */
 }
 
 static int table_grow(orc_table *t, int nl) {
@@ -509,7 +509,10 @@ static int insert_supermer(orc_ctx *c, orc_table *t, const char *sm, int len, ch
     if ((double)(t->num_elems + 1) > 0.66 * (double)t->capacity)
       if (table_grow(t, nl)) return -1;
     orc_vals *v = table_insert(t, km, nl);
-    if (!v) continue; /* dropped */
+    while (!v) { /* where the reference would drop, grow and retry: keeps dropped == 0 */
+      if (table_grow(t, nl)) return -1;
+      v = table_insert(t, km, nl);
+    }
     (*n_ins)++;
     /* S6 */
     int cnt = v->count + 1;

@@ -1,0 +1,281 @@
+"""Parity tests proper: the HIP path through the C ABI against the oracle, bit-exact
+(integer / byte / index work: no tolerance).  Need a real MI355X."""
+import numpy as np
+import pytest
+
+import mhm2_kmer_analysis_v2_amd as pkg
+from helpers import random_reads
+from oracle import cpu_oracle as O
+
+pytestmark = pytest.mark.gpu
+
+
+def oracle_run(bases, quals, offs, k, nranks=3, nthreads=2, dmin_thres=2):
+    o = O.Oracle(k, nranks=nranks, nthreads=nthreads, dmin_thres=dmin_thres)
+    o.add_reads(bases, quals, offs)
+    table = o.dump_table()
+    res = o.finalize()
+    st = o.stats()
+    assert st["dropped"] == 0
+    return res, table, st
+
+
+def assert_same(got, want):
+    for g, w, name in zip(got, want, ("keys", "counts", "left", "right")):
+        assert g.shape == w.shape, "%s: %s vs %s" % (name, g.shape, w.shape)
+        assert (g == w).all(), name
+
+
+def arrays(reads, quals):
+    return O.reads_to_arrays(reads, quals)
+
+
+@pytest.mark.parametrize("k", [21, 29, 33, 51, 55, 64, 77, 99])
+def test_random_reads_match_oracle(k):
+    rng = np.random.default_rng(100 + k)
+    reads, quals = random_reads(rng, 1500, min_len=max(3, k - 5), max_len=k + 130, genome_len=3000)
+    b, q, offs = arrays(reads, quals)
+    want, wtable, wst = oracle_run(b, q, offs, k)
+    with pkg.KmerCounter(k) as kc:
+        kc.submit_reads(b, q, offs)
+        kc.flush()
+        gtable = kc.dump_table()
+        got = kc.sorted_results()
+        st = kc.stats()
+    assert_same(got, want)
+    assert (gtable[0] == wtable[0]).all() and (gtable[1] == wtable[1]).all() and (gtable[2] == wtable[2]).all()
+    assert st["raw_kmers"] == wst["raw_kmers"]
+    assert st["kmers_inserted"] == wst["kmers_inserted"]
+    assert st["num_unique"] == wst["unique"]
+    assert st["num_purged"] == wst["purged"]
+    assert st["total_kmers"] == wst["total_kmers"] and st["sum_counts"] == wst["sum_counts"]
+    assert st["num_dropped"] == 0
+    assert len(got[1]) > 100
+
+
+def test_synthetic_arctic_shaped_reads_match_oracle():
+    p = pkg.synth_params(num_genomes=8, min_genome_len=30000, max_genome_len=60000, n_rate=0.001)
+    b, q, offs = pkg.synth_reads_host(30000, params=p)
+    for k in (21, 51):
+        want, _, wst = oracle_run(b, q, offs, k, nranks=4, nthreads=4)
+        got, st = pkg.analyze_kmers(k, 33, b, q, offs)
+        assert_same(got, want)
+        assert st["num_unique"] == wst["unique"] and st["sum_counts"] == wst["sum_counts"]
+
+
+def test_device_resident_input_and_unaligned_pointers():
+    import torch
+    k = 21
+    rng = np.random.default_rng(7)
+    reads, quals = random_reads(rng, 800, min_len=30, max_len=200, genome_len=2500)
+    b, q, offs = arrays(reads, quals)
+    want, _, _ = oracle_run(b, q, offs, k)
+    for shift_b, shift_q in ((0, 0), (1, 1), (7, 7), (15, 15), (3, 9)):
+        db = torch.zeros(len(b) + 64, dtype=torch.uint8, device="cuda")
+        dq = torch.zeros(len(q) + 64, dtype=torch.uint8, device="cuda")
+        db[shift_b:shift_b + len(b)] = torch.from_numpy(b).cuda()
+        dq[shift_q:shift_q + len(q)] = torch.from_numpy(q).cuda()
+        doff = torch.from_numpy(offs.astype(np.int64)).cuda()
+        torch.cuda.synchronize()
+        with pkg.KmerCounter(k) as kc:
+            kc.submit_reads(db[shift_b:], dq[shift_q:], doff, nreads=len(reads))
+            assert_same(kc.sorted_results(), want)
+
+
+def test_seq_block_format_matches_oracle():
+    # ParseAndPackGPUDriver::process_seq_block's input: case-masked reads joined by '_'
+    k = 21
+    rng = np.random.default_rng(8)
+    reads, quals = random_reads(rng, 600, min_len=15, max_len=160, genome_len=2000)
+    b, q, offs = arrays(reads, quals)
+    want, _, wst = oracle_run(b, q, offs, k)
+    masked = []
+    for r, ql in zip(reads, quals):
+        masked.append("".join(c.lower() if ord(x) < 33 + 20 else c for c, x in zip(r, ql)))
+    for block in ("_".join(masked), "_".join(masked) + "_", "_" + "__".join(masked)):
+        with pkg.KmerCounter(k) as kc:
+            kc.submit_seq_block(block.encode())
+            got = kc.sorted_results()
+            st = kc.stats()
+        assert_same(got, want)
+        assert st["raw_kmers"] == wst["raw_kmers"]
+
+
+def test_many_blocks_equal_one_block():
+    k = 33
+    rng = np.random.default_rng(9)
+    reads, quals = random_reads(rng, 900, min_len=20, max_len=150, genome_len=2500)
+    b, q, offs = arrays(reads, quals)
+    want, _, _ = oracle_run(b, q, offs, k)
+    with pkg.KmerCounter(k) as kc:
+        for r0 in range(0, 900, 100):
+            bb, qq, oo = arrays(reads[r0:r0 + 100], quals[r0:r0 + 100])
+            kc.submit_reads(bb, qq, oo)
+        assert_same(kc.sorted_results(), want)
+
+
+def test_sharded_flow_on_one_gpu():
+    """kc_extract_partition -> (exchange) -> kc_insert_records with three shards living on one
+    device: the union of the shards' results is the oracle's set and no k-mer has two owners."""
+    import torch
+    for k in (21, 51):
+        nl = pkg.lib().kc_num_longs(k)
+        rng = np.random.default_rng(10 + k)
+        reads, quals = random_reads(rng, 1000, min_len=30, max_len=150, genome_len=2500)
+        b, q, offs = arrays(reads, quals)
+        want, _, wst = oracle_run(b, q, offs, k)
+        R = 3
+        shards = [pkg.KmerCounter(k, rank_me=r, rank_n=R) for r in range(R)]
+        seg = int(wst["kmers_inserted"])  # worst case: everything to one shard
+        recs = torch.zeros(R * seg * nl, dtype=torch.int64, device="cuda")
+        # each "rank" parses a third of the reads and bins for all owners
+        for part in range(R):
+            sl = slice(part * 334, min(1000, (part + 1) * 334))
+            bb, qq, oo = arrays(reads[sl], quals[sl])
+            counts = shards[part].extract_partition(bb, qq, oo, recs, seg)
+            assert int(counts.sum()) == sum(max(0, len(r) - k - 1) for r in reads[sl])
+            for d in range(R):
+                shards[d].insert_records(recs[d * seg * nl:], int(counts[d]))
+                shards[d].flush()
+        parts = [s.sorted_results() for s in shards]
+        keys = np.concatenate([p[0] for p in parts])
+        order = np.lexsort([keys[:, j] for j in range(nl - 1, -1, -1)])
+        got = tuple(np.concatenate([p[i] for p in parts])[order] for i in range(4))
+        assert_same(got, want)
+        L = pkg.lib()
+        for r, p in enumerate(parts):
+            for i in range(0, len(p[1]), 37):
+                kw = np.ascontiguousarray(p[0][i])
+                assert L.kc_owner(kw.ctypes.data, k, R) == r
+        # too small a segment is reported, not silently truncated
+        with pytest.raises(pkg.KcError) as e:
+            shards[0].extract_partition(b, q, offs, recs, 10)
+        assert e.value.status == -6
+        for s in shards:
+            s.close()
+
+
+def test_local_filter_when_sharded():
+    # kc_submit_reads with rank_n > 1 inserts only the k-mers this shard owns
+    k = 21
+    rng = np.random.default_rng(12)
+    reads, quals = random_reads(rng, 500, min_len=30, max_len=150, genome_len=2000)
+    b, q, offs = arrays(reads, quals)
+    want, _, _ = oracle_run(b, q, offs, k)
+    parts = []
+    for r in range(2):
+        with pkg.KmerCounter(k, rank_me=r, rank_n=2) as kc:
+            kc.submit_reads(b, q, offs)
+            parts.append(kc.sorted_results())
+    keys = np.concatenate([p[0] for p in parts])
+    order = np.lexsort([keys[:, 0]])
+    got = tuple(np.concatenate([p[i] for p in parts])[order] for i in range(4))
+    assert_same(got, want)
+    assert len(parts[0][1]) > 0 and len(parts[1][1]) > 0
+
+
+def test_edge_cases():
+    k = 21
+    with pkg.KmerCounter(k) as kc:  # nothing submitted
+        assert len(kc.results()[1]) == 0
+    with pkg.KmerCounter(k) as kc:  # empty and too-short reads only
+        b, q, offs = arrays(["", "ACGT", "A" * 20, "ACGTACGTACGTACGTACGTA", "ACGTACGTACGTACGTACGTAC"], None)
+        kc.submit_reads(b, q, offs)
+        st = kc.stats()
+        assert len(kc.results()[1]) == 0
+        assert st["kmers_inserted"] == 0 and st["raw_kmers"] == 1 + 2
+    with pkg.KmerCounter(k) as kc:  # a byte outside ACGTN is an error (reference: DIE)
+        b, q, offs = arrays(["ACGTACGTACGTAC_TACGTACGTACGT"], None)
+        with pytest.raises(pkg.KcError) as e:
+            kc.submit_reads(b, q, offs)
+            kc.flush()
+        assert e.value.status == -7
+
+
+def test_hand_cases_small_k():
+    # the hand-derived cases of tests/test_oracle_end_to_end.py, through the GPU
+    cases = [
+        (["ACGTACGGA"] * 2, None, 5, [("CCGTA", 2, "T", "C")]),
+        (["AACCGTAG", "CTACGGTT"], None, 5, [("ACCGT", 2, "A", "A"), ("CCGTA", 2, "A", "G")]),
+        (["AACCGTAG"] * 2 + ["AACCGTAC"] * 2, None, 5, [("ACCGT", 4, "A", "A")]),
+        (["AACCGTAG"] * 2, ["IIIIIIII", "#IIIIIII"], 5, [("CCGTA", 2, "A", "G")]),
+        (["AACCNTAG", "AACCGTAG"], None, 5, [("ACCGT", 2, "A", "A"), ("CCGTA", 2, "A", "G")]),
+        (["TACGTC"] * 2, None, 4, [("ACGT", 2, "T", "C")]),
+    ]
+    for reads, quals, k, want in cases:
+        b, q, offs = arrays(reads, quals)
+        with pkg.KmerCounter(k) as kc:
+            kc.submit_reads(b, q, offs)
+            lines = kc.dump_lines()
+        assert lines == ["%s %d %s %s" % w for w in want], (reads, lines)
+
+
+def test_count_and_ext_saturation():
+    k = 5
+    unit = "AACCGTAG"
+    n = 70000
+    b, q, offs = arrays([unit] * n, None)
+    with pkg.KmerCounter(k) as kc:
+        kc.submit_reads(b, q, offs)
+        keys, counts, exts = kc.dump_table()
+        lines = kc.dump_lines()
+    assert int(counts.max()) == 65535 and int(exts.max()) == 65535
+    assert "ACCGT 65535 A A" in lines
+
+
+def test_table_grows_instead_of_dropping():
+    k = 21
+    rng = np.random.default_rng(13)
+    # ~400k distinct k-mers into a table created for 1k
+    genome = "".join(rng.choice(list("ACGT"), size=200000))
+    reads = [genome[i:i + 150] for i in range(0, 200000 - 150, 60)] * 2
+    b, q, offs = arrays(reads, None)
+    want, _, wst = oracle_run(b, q, offs, k, nranks=2)
+    with pkg.KmerCounter(k, max_elems=1000) as kc:
+        cap0 = kc.stats()["capacity"]
+        kc.submit_reads(b, q, offs)
+        got = kc.sorted_results()
+        st = kc.stats()
+    assert st["capacity"] > cap0 and st["num_dropped"] == 0
+    assert st["num_unique"] == wst["unique"]
+    assert_same(got, want)
+
+
+def test_reset_reuses_the_arena_across_k():
+    rng = np.random.default_rng(14)
+    reads, quals = random_reads(rng, 600, min_len=40, max_len=180, genome_len=2500)
+    b, q, offs = arrays(reads, quals)
+    with pkg.KmerCounter(21, max_elems=200000) as kc:
+        bytes0 = kc.stats()["table_bytes"]
+        for k in (21, 33, 55, 77, 21):
+            kc.reset(k)
+            kc.submit_reads(b, q, offs)
+            want, _, _ = oracle_run(b, q, offs, k)
+            assert_same(kc.sorted_results(), want)
+            assert kc.stats()["table_bytes"] == bytes0
+
+
+def test_dmin_thres_is_honoured():
+    k = 21
+    rng = np.random.default_rng(15)
+    reads, quals = random_reads(rng, 700, min_len=30, max_len=150, genome_len=1500)
+    b, q, offs = arrays(reads, quals)
+    for dmin in (1, 2, 3, 5):
+        want, _, _ = oracle_run(b, q, offs, k, dmin_thres=dmin)
+        with pkg.KmerCounter(k, dmin_thres=dmin) as kc:
+            kc.submit_reads(b, q, offs)
+            assert_same(kc.sorted_results(), want)
+
+
+def test_device_and_host_generators_agree():
+    import torch
+    p = pkg.synth_params(num_genomes=5, min_genome_len=3000, max_genome_len=9000, read_len=150, n_rate=0.002)
+    n = 5000
+    b, q, offs = pkg.synth_reads_host(n, first_read=123, params=p)
+    db = torch.empty(n * 150, dtype=torch.uint8, device="cuda")
+    dq = torch.empty(n * 150, dtype=torch.uint8, device="cuda")
+    do = torch.empty(n + 1, dtype=torch.int64, device="cuda")
+    with pkg.KmerCounter(21) as kc:
+        kc.synth_reads_device(db, dq, do, n, first_read=123, params=p)
+    assert (db.cpu().numpy() == b).all() and (dq.cpu().numpy() == q).all()
+    assert (do.cpu().numpy().astype(np.uint64) == offs).all()

@@ -411,7 +411,7 @@ static int ensure_stage(kc_ctx *c, size_t bytes, size_t reads, bool need_quals) 
 static int submit_reads_impl(kc_ctx *c, const uint8_t *bases, const uint8_t *quals, const uint64_t *offsets, uint64_t nreads,
                              int on_device, int mode, uint64_t *d_records, uint64_t seg_capacity) {
   if (!c || (nreads && (!bases || !quals || !offsets))) return KC_ERR_INVALID_ARG;
-  if (c->finalized) return KC_ERR_STATE;
+  if (c->finalized && mode == MODE_INSERT) return KC_ERR_STATE;  // extraction alone never touches the table
   HIPCHK(hipSetDevice(c->cfg.device));
   if (!nreads) return KC_OK;
   if (on_device) {

@@ -64,6 +64,7 @@ typedef struct kc_config {
 } kc_config;
 
 #define KC_FLAG_NONE 0u
+#define KC_FLAG_TIME_KERNELS 1u /* bracket every kernel launch with HIP events on its own stream (kc_get_kernel_times) */
 
 /* Scalars the reference logs (src/kcount/kcount.cpp:94-102,158-160;
  * src/kcount/kcount_cpu.cpp:495-521,586-598) plus table geometry. */
@@ -173,6 +174,17 @@ int kc_copy_results(kc_ctx *ctx, uint64_t *keys, uint16_t *counts, uint8_t *left
 int kc_dump_table(kc_ctx *ctx, uint64_t *keys, uint16_t *counts, uint16_t *exts, uint64_t *n);
 
 int kc_get_stats(kc_ctx *ctx, kc_stats *out);
+
+/* Per-kernel device time, measured with HIP events recorded on the stream the kernels are
+ * launched on (role of the reference's GPUTimer / get_elapsed_time, gpu_common.hpp:83-105,
+ * gpu_hash_table.hpp:172).  Needs KC_FLAG_TIME_KERNELS.  Fills up to max entries, *n = how many. */
+typedef struct kc_kernel_time {
+  char name[48];
+  uint64_t launches;
+  double total_ms;
+} kc_kernel_time;
+int kc_get_kernel_times(kc_ctx *ctx, kc_kernel_time *out, int max, int *n);
+int kc_clear_kernel_times(kc_ctx *ctx);
 
 /* ---- synthetic ArcticSynth-shaped reads (bench / tests) ------- */
 typedef struct kc_synth_params {

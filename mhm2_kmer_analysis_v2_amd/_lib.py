@@ -8,6 +8,7 @@ _LIB = None
 KC_OK = 0
 KC_ERR_CAPACITY = -6
 KC_ERR_BAD_BASE = -7
+KC_FLAG_TIME_KERNELS = 1
 
 
 class KcError(RuntimeError):
@@ -34,6 +35,10 @@ class kc_stats(C.Structure):
 class kc_result(C.Structure):
     _fields_ = [("n", C.c_uint64), ("num_longs", C.c_int32), ("reserved", C.c_int32), ("d_keys", C.c_void_p),
                 ("d_counts", C.c_void_p), ("d_left", C.c_void_p), ("d_right", C.c_void_p)]
+
+
+class kc_kernel_time(C.Structure):
+    _fields_ = [("name", C.c_char * 48), ("launches", C.c_uint64), ("total_ms", C.c_double)]
 
 
 class kc_synth_params(C.Structure):
@@ -64,6 +69,8 @@ SYMBOLS = {
     "kc_copy_results": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]),
     "kc_dump_table": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.POINTER(C.c_uint64)]),
     "kc_get_stats": (C.c_int, [C.c_void_p, C.POINTER(kc_stats)]),
+    "kc_get_kernel_times": (C.c_int, [C.c_void_p, C.POINTER(kc_kernel_time), C.c_int, C.POINTER(C.c_int)]),
+    "kc_clear_kernel_times": (C.c_int, [C.c_void_p]),
     "kc_synth_default_params": (None, [C.POINTER(kc_synth_params)]),
     "kc_synth_reads_host": (C.c_int, [C.POINTER(kc_synth_params), C.c_uint64, C.c_uint64, C.c_void_p, C.c_void_p, C.c_void_p]),
     "kc_synth_reads_device": (C.c_int, [C.c_void_p, C.POINTER(kc_synth_params), C.c_uint64, C.c_uint64, C.c_void_p, C.c_void_p,

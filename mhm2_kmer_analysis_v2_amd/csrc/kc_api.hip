@@ -34,8 +34,19 @@ static int hip_fail(hipError_t e, const char *what, int line) {
     if (e_ != hipSuccess) return hip_fail(e_, #call, __LINE__); \
   } while (0)
 
+enum { KT_EXTRACT_INSERT = 0, KT_EXTRACT_BIN, KT_INSERT_RECORDS, KT_FINALIZE, KT_TILE_FIRST, KT_REHASH, KT_COUNT };
+static const char *const kt_names[KT_COUNT] = {"kc_extract_kernel<insert>", "kc_extract_kernel<bin>", "kc_insert_records_kernel",
+                                               "kc_finalize_kernel", "kc_tile_first_kernel", "kc_rehash_kernel"};
+struct kt_pending {
+  hipEvent_t start, stop;
+  int kind;
+};
+
 struct kc_ctx {
   kc_config cfg;
+  std::vector<kt_pending> kt_pend;
+  uint64_t kt_launches[KT_COUNT];
+  double kt_ms[KT_COUNT];
   int k, nl;
   hipStream_t own_stream, stream;
   // table arena: keys then vals
@@ -63,7 +74,48 @@ struct kc_ctx {
   uint64_t purged, sum_counts, unique_at_finalize;
 };
 
+// ---- kernel timing (HIP events on the launch stream) --------------------------------------------
+struct KernelTimer {
+  kc_ctx *c;
+  kt_pending p;
+  bool on;
+  KernelTimer(kc_ctx *ctx, int kind);
+  ~KernelTimer();
+};
+
 // ---- small helpers -----------------------------------------------------------------------------
+KernelTimer::KernelTimer(kc_ctx *ctx, int kind) : c(ctx), on(false) {
+  ctx->num_gpu_calls++;
+  if (!(ctx->cfg.flags & KC_FLAG_TIME_KERNELS)) return;
+  p.kind = kind;
+  if (hipEventCreate(&p.start) != hipSuccess) return;
+  if (hipEventCreate(&p.stop) != hipSuccess) {
+    (void)hipEventDestroy(p.start);
+    return;
+  }
+  (void)hipEventRecord(p.start, ctx->stream);
+  on = true;
+}
+
+KernelTimer::~KernelTimer() {
+  if (!on) return;
+  (void)hipEventRecord(p.stop, c->stream);
+  c->kt_pend.push_back(p);
+}
+
+static void drain_kernel_times(kc_ctx *c) {  // stream must be idle
+  for (auto &p : c->kt_pend) {
+    float ms = 0;
+    if (hipEventElapsedTime(&ms, p.start, p.stop) == hipSuccess) {
+      c->kt_ms[p.kind] += ms;
+      c->kt_launches[p.kind]++;
+    }
+    (void)hipEventDestroy(p.start);
+    (void)hipEventDestroy(p.stop);
+  }
+  c->kt_pend.clear();
+}
+
 static uint64_t next_pow2(uint64_t v) {
   uint64_t p = 1;
   while (p < v) p <<= 1;
@@ -102,8 +154,10 @@ static int grow_table_nl(kc_ctx *c, uint64_t new_capacity) {
   HIPCHK(hipMemsetAsync(nt.keys, 0xFF, (size_t)new_capacity * NL * 8, c->stream));
   HIPCHK(hipMemsetAsync(nt.vals, 0, (size_t)new_capacity * 36, c->stream));
   const uint64_t nblk = (c->capacity + 255) / 256;
-  hipLaunchKernelGGL(kc_rehash_kernel<NL>, dim3((unsigned)nblk), dim3(256), 0, c->stream, c->table, c->capacity, nt);
-  c->num_gpu_calls++;
+  {
+    KernelTimer kt(c, KT_REHASH);
+    hipLaunchKernelGGL(kc_rehash_kernel<NL>, dim3((unsigned)nblk), dim3(256), 0, c->stream, c->table, c->capacity, nt);
+  }
   HIPCHK(hipGetLastError());
   HIPCHK(hipStreamSynchronize(c->stream));
   HIPCHK(hipFree(c->arena));
@@ -226,7 +280,6 @@ extern "C" kc_ctx *kc_create(const kc_config *cfg, int *status) {
     if (!c) st = KC_ERR_OUT_OF_MEMORY;
   }
   if (!st) {
-    memset(c, 0, sizeof(*c));
     c->cfg = *cfg;
     if (c->cfg.dmin_thres <= 0) c->cfg.dmin_thres = 2;
     c->k = cfg->kmer_len;
@@ -256,6 +309,7 @@ extern "C" void kc_destroy(kc_ctx *c) {
   if (!c) return;
   (void)hipSetDevice(c->cfg.device);
   if (c->stream) (void)hipStreamSynchronize(c->stream);
+  drain_kernel_times(c);
   free_results(c);
   if (c->arena) (void)hipFree(c->arena);
   if (c->d_ctrs) (void)hipFree(c->d_ctrs);
@@ -319,6 +373,7 @@ static void launch_extract_m(kc_ctx *c, const ExtractArgs &a, unsigned ntiles) {
 }
 
 static void launch_extract(kc_ctx *c, const ExtractArgs &a, unsigned ntiles, int mode, int fmt) {
+  KernelTimer kt(c, mode == MODE_INSERT ? KT_EXTRACT_INSERT : KT_EXTRACT_BIN);
   if (mode == MODE_INSERT) {
     if (fmt == FMT_READS) launch_extract_m<MODE_INSERT, FMT_READS>(c, a, ntiles);
     else launch_extract_m<MODE_INSERT, FMT_SEQBLOCK>(c, a, ntiles);
@@ -326,7 +381,6 @@ static void launch_extract(kc_ctx *c, const ExtractArgs &a, unsigned ntiles, int
     if (fmt == FMT_READS) launch_extract_m<MODE_BIN, FMT_READS>(c, a, ntiles);
     else launch_extract_m<MODE_BIN, FMT_SEQBLOCK>(c, a, ntiles);
   }
-  c->num_gpu_calls++;
 }
 
 // One block of device-resident input through the extract kernel, in chunks of tiles.
@@ -364,9 +418,11 @@ static int run_extract_device(kc_ctx *c, const uint8_t *bases, const uint8_t *qu
     if (fmt == FMT_READS) {
       int rc = ensure_tile_first(c, nt);
       if (rc) return rc;
-      hipLaunchKernelGGL(kc_tile_first_kernel, dim3((unsigned)((nt + 255) / 256)), dim3(256), 0, c->stream, d_offsets, nreads,
-                         a.align, t0, nt, c->d_tile_first);
-      c->num_gpu_calls++;
+      {
+        KernelTimer kt(c, KT_TILE_FIRST);
+        hipLaunchKernelGGL(kc_tile_first_kernel, dim3((unsigned)((nt + 255) / 256)), dim3(256), 0, c->stream, d_offsets, nreads,
+                           a.align, t0, nt, c->d_tile_first);
+      }
       a.tile_first = c->d_tile_first;
     }
     a.tile0 = t0;
@@ -517,13 +573,15 @@ extern "C" int kc_insert_records(kc_ctx *c, const uint64_t *d_records, uint64_t 
     int rc = ensure_room(c, m);
     if (rc) return rc;
     const uint64_t *p = d_records + done * c->nl;
-    switch (c->nl) {
-      case 1: launch_insert_records<1>(c, p, m); break;
-      case 2: launch_insert_records<2>(c, p, m); break;
-      case 3: launch_insert_records<3>(c, p, m); break;
-      default: launch_insert_records<4>(c, p, m); break;
+    {
+      KernelTimer kt(c, KT_INSERT_RECORDS);
+      switch (c->nl) {
+        case 1: launch_insert_records<1>(c, p, m); break;
+        case 2: launch_insert_records<2>(c, p, m); break;
+        case 3: launch_insert_records<3>(c, p, m); break;
+        default: launch_insert_records<4>(c, p, m); break;
+      }
     }
-    c->num_gpu_calls++;
     HIPCHK(hipGetLastError());
     done += m;
   }
@@ -563,13 +621,15 @@ extern "C" int kc_finalize(kc_ctx *c, kc_result *out) {
     HIPCHK(hipMalloc((void **)&c->d_out_right, cap));
     c->out_cap = cap;
     HIPCHK(hipMemsetAsync(c->d_ctrs + CTR_OUT, 0, 3 * 8, c->stream));  // OUT, PURGED, SUM_COUNTS
-    switch (c->nl) {
-      case 1: launch_finalize<1>(c); break;
-      case 2: launch_finalize<2>(c); break;
-      case 3: launch_finalize<3>(c); break;
-      default: launch_finalize<4>(c); break;
+    {
+      KernelTimer kt(c, KT_FINALIZE);
+      switch (c->nl) {
+        case 1: launch_finalize<1>(c); break;
+        case 2: launch_finalize<2>(c); break;
+        case 3: launch_finalize<3>(c); break;
+        default: launch_finalize<4>(c); break;
+      }
     }
-    c->num_gpu_calls++;
     HIPCHK(hipGetLastError());
     rc = sync_ctrs(c);
     if (rc) return rc;
@@ -657,6 +717,38 @@ extern "C" int kc_get_stats(kc_ctx *c, kc_stats *o) {
   o->capacity = c->capacity;
   o->num_gpu_calls = c->num_gpu_calls;
   o->table_bytes = c->arena_bytes;
+  return KC_OK;
+}
+
+extern "C" int kc_get_kernel_times(kc_ctx *c, kc_kernel_time *out, int max, int *n) {
+  if (!c || !n) return KC_ERR_INVALID_ARG;
+  HIPCHK(hipSetDevice(c->cfg.device));
+  HIPCHK(hipStreamSynchronize(c->stream));
+  drain_kernel_times(c);
+  int m = 0;
+  for (int i = 0; i < KT_COUNT; i++) {
+    if (!c->kt_launches[i]) continue;
+    if (out && m < max) {
+      memset(&out[m], 0, sizeof(out[m]));
+      snprintf(out[m].name, sizeof(out[m].name), "%s", kt_names[i]);
+      out[m].launches = c->kt_launches[i];
+      out[m].total_ms = c->kt_ms[i];
+    }
+    m++;
+  }
+  *n = m;
+  return KC_OK;
+}
+
+extern "C" int kc_clear_kernel_times(kc_ctx *c) {
+  if (!c) return KC_ERR_INVALID_ARG;
+  HIPCHK(hipSetDevice(c->cfg.device));
+  HIPCHK(hipStreamSynchronize(c->stream));
+  drain_kernel_times(c);
+  for (int i = 0; i < KT_COUNT; i++) {
+    c->kt_launches[i] = 0;
+    c->kt_ms[i] = 0;
+  }
   return KC_OK;
 }
 

@@ -1,0 +1,83 @@
+"""Shard exchange for the multi-GPU flow: one process per GPU, torch.distributed
+(backend "nccl" = RCCL over xGMI on the GPU box, "gloo" in the CPU tests).
+
+Replaces the reference's only bulk exchange, the aggregated UPC++ RPC of
+ThreeTierAggrStore::update (src/kcount/kmer_dht.cpp:143-151,247-258), inside the
+node: per block of reads every rank bins its k-mer records by owner shard
+(kc_extract_partition), the ranks swap the per-shard counts (an N x N all-to-all of
+int64), then the records themselves (all-to-all-v as grouped send/recv), and each
+rank inserts what it received (kc_insert_records).  Nothing else is communicated:
+ownership is a pure function of the k-mer, finalize is per shard.
+"""
+import torch
+import torch.distributed as dist
+
+
+def exchange_counts(send_counts, group=None):
+    """send_counts: int64 tensor [world] (records for each destination).  Returns recv_counts [world]."""
+    recv = torch.empty_like(send_counts)
+    dist.all_to_all_single(recv, send_counts, group=group)
+    return recv
+
+
+def exchange_records(send, send_counts, recv_counts, seg_capacity, num_longs, recv=None, group=None):
+    """send: int64 tensor laid out as world segments of seg_capacity records (num_longs words each), the
+    first send_counts[d] records of segment d being valid.  Returns (recv tensor, n_received): the received
+    records packed back to back."""
+    world = dist.get_world_size(group)
+    sc = [int(x) for x in send_counts.tolist()]
+    rc = [int(x) for x in recv_counts.tolist()]
+    total = sum(rc)
+    if recv is None or recv.numel() < max(total, 1) * num_longs:
+        recv = torch.empty(max(total, 1) * num_longs, dtype=send.dtype, device=send.device)
+    # all-to-all-v as one group of point-to-point transfers (RCCL: a single ncclGroup of
+    # ncclSend/ncclRecv over xGMI; gloo: the same ops over TCP).  The segments of `send` are not
+    # contiguous, so a single-buffer all_to_all_single would need an extra packing pass over HBM.
+    me = dist.get_rank(group)
+    ops = []
+    pos = 0
+    for d in range(world):
+        base = d * seg_capacity * num_longs
+        src = send[base:base + sc[d] * num_longs]
+        dst = recv[pos:pos + rc[d] * num_longs]
+        pos += rc[d] * num_longs
+        if d == me:
+            dst.copy_(src)
+            continue
+        if rc[d]:
+            ops.append(dist.P2POp(dist.irecv, dst, dist.get_global_rank(group, d) if group is not None else d, group))
+        if sc[d]:
+            ops.append(dist.P2POp(dist.isend, src, dist.get_global_rank(group, d) if group is not None else d, group))
+    if ops:
+        for w in dist.batch_isend_irecv(ops):
+            w.wait()
+    return recv, total
+
+
+class ShardedKmerAnalysis:
+    """count_kmers + flush_updates + finish_updates (src/kcount/kcount.cpp:54-104,142-161) across the ranks
+    of one node.  `extract(block, send, seg_capacity) -> counts` and `insert(recv, n)` are the two device
+    entry points (KmerCounter.extract_partition / insert_records on the GPU; the CPU tests plug in stand-ins
+    so that the exchange logic itself is what they exercise)."""
+
+    def __init__(self, extract, insert, num_longs, seg_capacity, device, group=None):
+        self.extract, self.insert = extract, insert
+        self.nl, self.seg = num_longs, seg_capacity
+        self.group = group
+        self.world = dist.get_world_size(group)
+        self.device = device
+        self.send = torch.zeros(self.world * seg_capacity * num_longs, dtype=torch.int64, device=device)
+        self.recv = None
+        self.sent = 0
+        self.received = 0
+
+    def add_block(self, block):
+        counts = self.extract(block, self.send, self.seg)
+        sc = torch.as_tensor([int(c) for c in counts], dtype=torch.int64, device=self.device)
+        rc = exchange_counts(sc, self.group)
+        self.recv, n = exchange_records(self.send, sc.cpu(), rc.cpu(), self.seg, self.nl, self.recv, self.group)
+        if n:
+            self.insert(self.recv, n)
+        self.sent += int(sc.sum())
+        self.received += n
+        return n

@@ -14,7 +14,7 @@ import ctypes as C
 import numpy as np
 
 from . import _lib
-from ._lib import check, kc_config, kc_result, kc_stats, kc_synth_params, lib
+from ._lib import check, kc_config, kc_kernel_time, kc_result, kc_stats, kc_synth_params, lib
 
 
 def _ptr(a):
@@ -53,10 +53,10 @@ def synth_reads_host(nreads, first_read=0, params=None):
 class KmerCounter:
     """One shard (one GPU) of the k-mer analysis stage."""
 
-    def __init__(self, kmer_len, qual_offset=33, dmin_thres=2, device=0, rank_me=0, rank_n=1, max_elems=0):
+    def __init__(self, kmer_len, qual_offset=33, dmin_thres=2, device=0, rank_me=0, rank_n=1, max_elems=0, time_kernels=False):
         L = lib()
         cfg = kc_config(kmer_len=kmer_len, qual_offset=qual_offset, dmin_thres=dmin_thres, device=device, rank_me=rank_me,
-                        rank_n=rank_n, max_elems=max_elems, flags=0, reserved=0)
+                        rank_n=rank_n, max_elems=max_elems, flags=_lib.KC_FLAG_TIME_KERNELS if time_kernels else 0, reserved=0)
         st = C.c_int(0)
         self._h = L.kc_create(C.byref(cfg), C.byref(st))
         if not self._h:
@@ -164,6 +164,16 @@ class KmerCounter:
         s = kc_stats()
         check(lib().kc_get_stats(self._h, C.byref(s)), "kc_get_stats")
         return {n: int(getattr(s, n)) for n, _ in kc_stats._fields_}
+
+    def kernel_times(self, clear=False):
+        """{kernel name: (launches, total_ms)} from HIP events on the launch stream (needs time_kernels=True)."""
+        arr = (kc_kernel_time * 16)()
+        n = C.c_int(0)
+        check(lib().kc_get_kernel_times(self._h, arr, 16, C.byref(n)), "kc_get_kernel_times")
+        out = {arr[i].name.decode(): (int(arr[i].launches), float(arr[i].total_ms)) for i in range(min(n.value, 16))}
+        if clear:
+            check(lib().kc_clear_kernel_times(self._h), "kc_clear_kernel_times")
+        return out
 
     def synth_reads_device(self, d_bases, d_quals, d_offsets, nreads, first_read=0, params=None):
         p = params or synth_params()

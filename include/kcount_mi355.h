@@ -61,6 +61,10 @@ typedef struct kc_config {
   uint64_t max_elems;
   uint32_t flags; /* KC_FLAG_* */
   uint32_t reserved;
+  /* k-mer occurrences the context can hold between kc_reset and kc_finalize on its fast (bucketed)
+   * path; beyond it the context keeps working through its slower global-table path.  Role of the
+   * reference's my_num_kmers estimate (src/contigging.cpp:86).  0 = 64 Mi. */
+  uint64_t max_kmers_buffered;
 } kc_config;
 
 #define KC_FLAG_NONE 0u
@@ -174,6 +178,21 @@ int kc_copy_results(kc_ctx *ctx, uint64_t *keys, uint16_t *counts, uint8_t *left
 int kc_dump_table(kc_ctx *ctx, uint64_t *keys, uint16_t *counts, uint16_t *exts, uint64_t *n);
 
 int kc_get_stats(kc_ctx *ctx, kc_stats *out);
+
+/* Geometry of the bucketed insert path; 0 in a field keeps the automatic choice.  Only for tests
+ * (forcing the overflow paths with tiny capacities) and tuning runs; call right after
+ * kc_create / kc_reset, before the first submit. */
+typedef struct kc_tuning {
+  uint32_t mode;          /* 0 auto (bucketed), 1 global-table path only */
+  uint32_t writers;       /* level-1 writer workgroups (<= 1024) */
+  uint32_t p1, p2;        /* fan-out of level 1 / level 2: powers of two <= 1024 */
+  uint32_t slots;         /* LDS slots per region */
+  uint32_t reserved;
+  uint64_t seg_capacity;  /* records per (writer, bucket) segment */
+  uint64_t reg_capacity;  /* records per region */
+  uint64_t ovf_capacity;  /* records per overflow list */
+} kc_tuning;
+int kc_set_tuning(kc_ctx *ctx, const kc_tuning *t);
 
 /* Per-kernel device time, measured with HIP events recorded on the stream the kernels are
  * launched on (role of the reference's GPUTimer / get_elapsed_time, gpu_common.hpp:83-105,

@@ -23,7 +23,7 @@ class KcError(RuntimeError):
 class kc_config(C.Structure):
     _fields_ = [("kmer_len", C.c_int32), ("qual_offset", C.c_int32), ("dmin_thres", C.c_int32), ("device", C.c_int32),
                 ("rank_me", C.c_int32), ("rank_n", C.c_int32), ("max_elems", C.c_uint64), ("flags", C.c_uint32),
-                ("reserved", C.c_uint32)]
+                ("reserved", C.c_uint32), ("max_kmers_buffered", C.c_uint64)]
 
 
 class kc_stats(C.Structure):
@@ -35,6 +35,12 @@ class kc_stats(C.Structure):
 class kc_result(C.Structure):
     _fields_ = [("n", C.c_uint64), ("num_longs", C.c_int32), ("reserved", C.c_int32), ("d_keys", C.c_void_p),
                 ("d_counts", C.c_void_p), ("d_left", C.c_void_p), ("d_right", C.c_void_p)]
+
+
+class kc_tuning(C.Structure):
+    _fields_ = [("mode", C.c_uint32), ("writers", C.c_uint32), ("p1", C.c_uint32), ("p2", C.c_uint32), ("slots", C.c_uint32),
+                ("reserved", C.c_uint32), ("seg_capacity", C.c_uint64), ("reg_capacity", C.c_uint64),
+                ("ovf_capacity", C.c_uint64)]
 
 
 class kc_kernel_time(C.Structure):
@@ -69,6 +75,7 @@ SYMBOLS = {
     "kc_copy_results": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]),
     "kc_dump_table": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.POINTER(C.c_uint64)]),
     "kc_get_stats": (C.c_int, [C.c_void_p, C.POINTER(kc_stats)]),
+    "kc_set_tuning": (C.c_int, [C.c_void_p, C.POINTER(kc_tuning)]),
     "kc_get_kernel_times": (C.c_int, [C.c_void_p, C.POINTER(kc_kernel_time), C.c_int, C.POINTER(C.c_int)]),
     "kc_clear_kernel_times": (C.c_int, [C.c_void_p]),
     "kc_synth_default_params": (None, [C.POINTER(kc_synth_params)]),

@@ -17,7 +17,7 @@
 #include <vector>
 
 #include "../../include/kcount_mi355.h"
-#include "kc_kernels.hpp"
+#include "kc_bucketed.hpp"
 
 using namespace kc;
 
@@ -34,9 +34,12 @@ static int hip_fail(hipError_t e, const char *what, int line) {
     if (e_ != hipSuccess) return hip_fail(e_, #call, __LINE__); \
   } while (0)
 
-enum { KT_EXTRACT_INSERT = 0, KT_EXTRACT_BIN, KT_INSERT_RECORDS, KT_FINALIZE, KT_TILE_FIRST, KT_REHASH, KT_COUNT };
+enum { KT_EXTRACT_INSERT = 0, KT_EXTRACT_BIN, KT_INSERT_RECORDS, KT_FINALIZE, KT_TILE_FIRST, KT_REHASH, KT_L1_READS, KT_L1_RECORDS,
+       KT_L2_SPLIT, KT_COUNT_REGIONS, KT_FALLBACK, KT_COUNT };
 static const char *const kt_names[KT_COUNT] = {"kc_extract_kernel<insert>", "kc_extract_kernel<bin>", "kc_insert_records_kernel",
-                                               "kc_finalize_kernel", "kc_tile_first_kernel", "kc_rehash_kernel"};
+                                               "kc_finalize_kernel", "kc_tile_first_kernel", "kc_rehash_kernel",
+                                               "kc_l1_reads_kernel", "kc_l1_records_kernel", "kc_l2_split_kernel",
+                                               "kc_count_kernel", "kc_flagged_to_table_kernel"};
 struct kt_pending {
   hipEvent_t start, stop;
   int kind;
@@ -72,9 +75,26 @@ struct kc_ctx {
   // host-side stats
   uint64_t num_reads, num_bases, num_gpu_calls;
   uint64_t purged, sum_counts, unique_at_finalize;
+  // bucketed path (kc_bucketed.hpp)
+  kc_tuning tuning;
+  bool bk_ready;      // buffers allocated for the current geometry
+  bool bk_level2;     // regions built for the buffered records
+  bool bk_flagged;    // flagged regions and overflow records already moved to the global table
+  bool table_mode;    // everything goes through the global table from now on
+  bool started;       // something was submitted since create/reset
+  Geom gm;
+  BucketBufs bb;
+  uint64_t *d_cb, *h_cb;
+  uint64_t bk_capacity;  // records the level-1 segments are sized for
+  uint64_t bk_buffered;  // upper bound of records buffered so far (positions submitted)
+  uint32_t bk_rot;       // first writer of the next level-1 launch
+  size_t bk_bytes;
+  int num_cus;
 };
 
 // ---- kernel timing (HIP events on the launch stream) --------------------------------------------
+static void bk_free(kc_ctx *c);
+
 struct KernelTimer {
   kc_ctx *c;
   kt_pending p;
@@ -251,15 +271,21 @@ static int create_impl(kc_ctx *c) {
   HIPCHK(hipSetDevice(c->cfg.device));
   HIPCHK(hipStreamCreateWithFlags(&c->own_stream, hipStreamNonBlocking));
   c->stream = c->own_stream;
-  uint64_t want = c->cfg.max_elems ? c->cfg.max_elems : (1ULL << 24);
-  c->capacity = next_pow2((uint64_t)((double)want / 0.6) + 1);
-  if (c->capacity < (1ULL << 16)) c->capacity = 1ULL << 16;
+  hipDeviceProp_t prop;
+  HIPCHK(hipGetDeviceProperties(&prop, c->cfg.device));
+  c->num_cus = prop.multiProcessorCount > 0 ? prop.multiProcessorCount : 256;
+  // the global table starts small: on the bucketed path it only ever holds the regions that did not fit
+  c->capacity = 1ULL << 16;
   c->arena_bytes = table_bytes_for(c->capacity, c->nl);
   HIPCHK(hipMalloc((void **)&c->arena, c->arena_bytes));
   carve_table(c);
   HIPCHK(hipMalloc((void **)&c->d_ctrs, CTR_COUNT * 8));
   HIPCHK(hipHostMalloc((void **)&c->h_ctrs, CTR_COUNT * 8, hipHostMallocDefault));
   HIPCHK(hipMemsetAsync(c->d_ctrs, 0, CTR_COUNT * 8, c->stream));
+  HIPCHK(hipMalloc((void **)&c->d_cb, CB_COUNT * 8));
+  HIPCHK(hipHostMalloc((void **)&c->h_cb, CB_COUNT * 8, hipHostMallocDefault));
+  HIPCHK(hipMemsetAsync(c->d_cb, 0, CB_COUNT * 8, c->stream));
+  memset(c->h_cb, 0, CB_COUNT * 8);
   int rc = clear_table(c);
   if (rc) return rc;
   HIPCHK(hipStreamSynchronize(c->stream));
@@ -319,6 +345,9 @@ extern "C" void kc_destroy(kc_ctx *c) {
   if (c->d_stage_quals) (void)hipFree(c->d_stage_quals);
   if (c->d_stage_offsets) (void)hipFree(c->d_stage_offsets);
   if (c->d_synth) (void)hipFree(c->d_synth);
+  bk_free(c);
+  if (c->d_cb) (void)hipFree(c->d_cb);
+  if (c->h_cb) (void)hipHostFree(c->h_cb);
   if (c->own_stream) (void)hipStreamDestroy(c->own_stream);
   delete c;
 }
@@ -338,6 +367,7 @@ extern "C" int kc_reset(kc_ctx *c, int new_k) {
   HIPCHK(hipSetDevice(c->cfg.device));
   HIPCHK(hipStreamSynchronize(c->stream));
   free_results(c);
+  const int old_nl = c->nl;
   c->k = new_k;
   c->cfg.kmer_len = new_k;
   c->nl = kc_num_longs(new_k);
@@ -352,9 +382,207 @@ extern "C" int kc_reset(kc_ctx *c, int new_k) {
   c->finalized = false;
   c->num_reads = c->num_bases = 0;
   c->purged = c->sum_counts = c->unique_at_finalize = 0;
+  // bucketed path: keep the arrays when the record width is unchanged, else choose the geometry again
+  if (c->bk_ready) {
+    if (c->nl != old_nl) {
+      bk_free(c);
+    } else {
+      const size_t R = (size_t)c->gm.P1 * c->gm.P2;
+      HIPCHK(hipMemsetAsync(c->bb.cnt1, 0, (size_t)c->gm.G * c->gm.P1 * 4, c->stream));
+      HIPCHK(hipMemsetAsync(c->bb.cnt2, 0, R * 4, c->stream));
+      HIPCHK(hipMemsetAsync(c->bb.flag, 0, R * 4, c->stream));
+    }
+  }
+  HIPCHK(hipMemsetAsync(c->d_cb, 0, CB_COUNT * 8, c->stream));
+  c->bk_level2 = c->bk_flagged = c->table_mode = c->started = false;
   HIPCHK(hipStreamSynchronize(c->stream));
   return KC_OK;
 }
+
+// ---- bucketed path: geometry, buffers, launches (kernels in kc_bucketed.hpp) ------------------------
+static uint32_t count_smax(int nl) {
+  switch (nl) {
+    case 1: return CountLDS<1>::SMAX;
+    case 2: return CountLDS<2>::SMAX;
+    case 3: return CountLDS<3>::SMAX;
+    default: return CountLDS<4>::SMAX;
+  }
+}
+
+static void bk_free(kc_ctx *c) {
+  BucketBufs &b = c->bb;
+  if (b.rec1) (void)hipFree(b.rec1);
+  if (b.cnt1) (void)hipFree(b.cnt1);
+  if (b.rec2) (void)hipFree(b.rec2);
+  if (b.cnt2) (void)hipFree(b.cnt2);
+  if (b.flag) (void)hipFree(b.flag);
+  if (b.ovf1) (void)hipFree(b.ovf1);
+  if (b.ovf2) (void)hipFree(b.ovf2);
+  memset(&b, 0, sizeof(b));
+  c->bk_ready = false;
+  c->bk_bytes = 0;
+}
+
+static uint32_t ilog2(uint64_t v) {
+  uint32_t l = 0;
+  while ((1ULL << l) < v) l++;
+  return l;
+}
+
+static uint64_t padded_capacity(double mean, double heavy) {
+  // Poisson slack (6 sigma) + room for heavy-hitter k-mers + a floor for tiny inputs
+  return (uint64_t)(mean + 6.0 * sqrt(mean) + heavy * mean) + 64;
+}
+
+// Choose the geometry from the configured sizes and allocate the level-1 / level-2 arrays.
+static int bk_init(kc_ctx *c) {
+  if (c->bk_ready) return KC_OK;
+  const kc_tuning &t = c->tuning;
+  Geom &g = c->gm;
+  const uint64_t bcap = c->cfg.max_kmers_buffered ? c->cfg.max_kmers_buffered : (1ULL << 26);
+  const double est = c->cfg.max_elems ? (double)c->cfg.max_elems : 0.35 * (double)bcap;  // 1/depth(4) + error share, kmer_dht.cpp:126-131
+  const uint32_t smax = count_smax(c->nl);
+  g.S = t.slots ? std::min(std::max(t.slots, 16u), smax) : smax;
+  const uint64_t regions_needed = (uint64_t)(est / (0.7 * g.S)) + 1;  // LDS tables run at ~0.7 load
+  uint32_t bits = std::min<uint32_t>(ilog2(regions_needed), 20);
+  g.log2P1 = t.p1 ? ilog2(t.p1) : bits / 2;  // level 1 holds fewer records per round than level 2: give it the smaller fan-out
+  g.log2P2 = t.p2 ? ilog2(t.p2) : (bits + 1) / 2;
+  if (g.log2P1 > 10 || g.log2P2 > 10) return KC_ERR_INVALID_ARG;
+  g.P1 = 1u << g.log2P1;
+  g.P2 = 1u << g.log2P2;
+  // one writer per CU, but never so many that a writer's share of the buffer is below a few rounds of records
+  g.G = t.writers ? std::min<uint32_t>(t.writers, GMAX)
+                  : (uint32_t)std::max<uint64_t>(1, std::min<uint64_t>((uint64_t)std::min<int>(c->num_cus, GMAX), bcap / (4 * 16384)));
+  if (g.G < 1) g.G = 1;
+  const uint64_t R = (uint64_t)g.P1 * g.P2;
+  g.C1 = t.seg_capacity ? t.seg_capacity : padded_capacity((double)bcap / ((double)g.G * g.P1), 0.08);
+  g.C2 = t.reg_capacity ? t.reg_capacity : padded_capacity((double)bcap / (double)R, 0.15);
+  if (g.C1 >= (1ULL << 31) || g.C2 >= (1ULL << 31) || bcap / g.P1 >= (1ULL << 31)) return KC_ERR_INVALID_ARG;
+  BucketBufs &b = c->bb;
+  memset(&b, 0, sizeof(b));
+  b.ovf1_cap = b.ovf2_cap = t.ovf_capacity ? t.ovf_capacity : bcap / 16 + 4096;
+  const size_t w = (size_t)c->nl * 8;
+  const size_t nseg = (size_t)g.G * g.P1;
+  HIPCHK(hipMalloc((void **)&b.rec1, nseg * g.C1 * w));
+  HIPCHK(hipMalloc((void **)&b.cnt1, nseg * 4));
+  HIPCHK(hipMalloc((void **)&b.rec2, (size_t)R * g.C2 * w));
+  HIPCHK(hipMalloc((void **)&b.cnt2, (size_t)R * 4));
+  HIPCHK(hipMalloc((void **)&b.flag, (size_t)R * 4));
+  HIPCHK(hipMalloc((void **)&b.ovf1, b.ovf1_cap * w));
+  HIPCHK(hipMalloc((void **)&b.ovf2, b.ovf2_cap * w));
+  HIPCHK(hipMemsetAsync(b.cnt1, 0, nseg * 4, c->stream));
+  HIPCHK(hipMemsetAsync(b.cnt2, 0, (size_t)R * 4, c->stream));
+  HIPCHK(hipMemsetAsync(b.flag, 0, (size_t)R * 4, c->stream));
+  HIPCHK(hipMemsetAsync(c->d_cb, 0, CB_COUNT * 8, c->stream));
+  c->bk_bytes = nseg * g.C1 * w + (size_t)R * g.C2 * w + (b.ovf1_cap + b.ovf2_cap) * w + nseg * 4 + (size_t)R * 8;
+  c->bk_capacity = bcap;
+  c->bk_ready = true;
+  c->bk_level2 = c->bk_flagged = false;
+  return KC_OK;
+}
+
+static int sync_cb(kc_ctx *c) {
+  HIPCHK(hipMemcpyAsync(c->h_cb, c->d_cb, CB_COUNT * 8, hipMemcpyDeviceToHost, c->stream));
+  HIPCHK(hipStreamSynchronize(c->stream));
+  return KC_OK;
+}
+
+template <typename K>
+static int set_dyn_lds(K kernel, size_t bytes) {
+  HIPCHK(hipFuncSetAttribute((const void *)kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)bytes));
+  return KC_OK;
+}
+
+static size_t lds_l1_reads() { return ((sizeof(L1LDS) + 15) & ~size_t(15)) + STAGE_BYTES; }
+static size_t lds_l1_records() { return ((sizeof(L1RLDS) + 15) & ~size_t(15)) + STAGE_BYTES; }
+static size_t lds_l2() { return ((sizeof(L2LDS) + 15) & ~size_t(15)) + STAGE_BYTES; }
+
+template <int NL, int FMT>
+static int launch_l1_reads_t(kc_ctx *c, const ExtractArgs &a, uint64_t ntiles) {
+  auto kern = kc_l1_reads_kernel<NL, FMT>;
+  int rc = set_dyn_lds(kern, lds_l1_reads());
+  if (rc) return rc;
+  const uint64_t nsuper = (ntiles + QUARTERS - 1) / QUARTERS;
+  const unsigned grid = (unsigned)std::min<uint64_t>(c->gm.G, nsuper);
+  KernelTimer kt(c, KT_L1_READS);
+  hipLaunchKernelGGL(kern, dim3(grid), dim3(WGB), lds_l1_reads(), c->stream, a, c->gm, c->bb, ntiles, c->bk_rot, c->d_ctrs, c->d_cb);
+  c->bk_rot = (uint32_t)((c->bk_rot + nsuper) % c->gm.G);
+  return KC_OK;
+}
+
+static int launch_l1_reads(kc_ctx *c, const ExtractArgs &a, uint64_t ntiles, int fmt) {
+  if (fmt == FMT_READS) {
+    switch (c->nl) {
+      case 1: return launch_l1_reads_t<1, FMT_READS>(c, a, ntiles);
+      case 2: return launch_l1_reads_t<2, FMT_READS>(c, a, ntiles);
+      case 3: return launch_l1_reads_t<3, FMT_READS>(c, a, ntiles);
+      default: return launch_l1_reads_t<4, FMT_READS>(c, a, ntiles);
+    }
+  }
+  switch (c->nl) {
+    case 1: return launch_l1_reads_t<1, FMT_SEQBLOCK>(c, a, ntiles);
+    case 2: return launch_l1_reads_t<2, FMT_SEQBLOCK>(c, a, ntiles);
+    case 3: return launch_l1_reads_t<3, FMT_SEQBLOCK>(c, a, ntiles);
+    default: return launch_l1_reads_t<4, FMT_SEQBLOCK>(c, a, ntiles);
+  }
+}
+
+template <int NL>
+static int launch_l1_records_t(kc_ctx *c, const uint64_t *recs, uint64_t n) {
+  auto kern = kc_l1_records_kernel<NL>;
+  int rc = set_dyn_lds(kern, lds_l1_records());
+  if (rc) return rc;
+  const uint64_t per_round = (uint64_t)WGB * Rnd<NL>::RPOS;
+  const unsigned grid = (unsigned)std::min<uint64_t>(c->gm.G, (n + per_round - 1) / per_round);
+  KernelTimer kt(c, KT_L1_RECORDS);
+  hipLaunchKernelGGL(kern, dim3(grid), dim3(WGB), lds_l1_records(), c->stream, recs, n, c->gm, c->bb, c->bk_rot, c->d_ctrs, c->d_cb);
+  c->bk_rot = (uint32_t)((c->bk_rot + (n + per_round - 1) / per_round) % c->gm.G);
+  return KC_OK;
+}
+
+template <int NL>
+static int bk_drain_t(kc_ctx *c) {
+  {
+    KernelTimer kt(c, KT_FALLBACK);
+    hipLaunchKernelGGL(kc_l1_to_table_kernel<NL>, dim3((unsigned)std::min<size_t>((size_t)c->gm.G * c->gm.P1, 65536)), dim3(TPB), 0, c->stream,
+                       c->gm, c->bb, c->table, c->d_ctrs);
+  }
+  const uint64_t n1 = std::min<uint64_t>(c->h_cb[CB_OVF1], c->bb.ovf1_cap);
+  if (n1) {
+    KernelTimer kt(c, KT_INSERT_RECORDS);
+    unsigned nblk = (unsigned)std::min<uint64_t>((n1 + TPB - 1) / TPB, 256 * 32);
+    hipLaunchKernelGGL(kc_insert_records_kernel<NL>, dim3(nblk), dim3(TPB), 0, c->stream, c->bb.ovf1, n1, c->table, c->d_ctrs, 0u);
+  }
+  return KC_OK;
+}
+
+// The buffer is full: move everything buffered into the global table and stay on the table path.
+static int bk_drain_to_table(kc_ctx *c) {
+  int rc = sync_ctrs(c);
+  if (rc) return rc;
+  rc = sync_cb(c);
+  if (rc) return rc;
+  if (c->h_cb[CB_FATAL]) {
+    snprintf(g_last_error, sizeof(g_last_error), "k-mer buffer overflow lists exhausted: raise max_kmers_buffered");
+    return KC_ERR_CAPACITY;
+  }
+  rc = ensure_room(c, c->h_ctrs[CTR_INSERTED]);
+  if (rc) return rc;
+  switch (c->nl) {
+    case 1: rc = bk_drain_t<1>(c); break;
+    case 2: rc = bk_drain_t<2>(c); break;
+    case 3: rc = bk_drain_t<3>(c); break;
+    default: rc = bk_drain_t<4>(c); break;
+  }
+  if (rc) return rc;
+  HIPCHK(hipGetLastError());
+  HIPCHK(hipMemsetAsync(c->bb.cnt1, 0, (size_t)c->gm.G * c->gm.P1 * 4, c->stream));
+  HIPCHK(hipMemsetAsync(c->d_cb, 0, CB_COUNT * 8, c->stream));
+  c->table_mode = true;
+  return KC_OK;
+}
+
+static bool bk_active(const kc_ctx *c) { return c->tuning.mode == 0 && !c->table_mode; }
 
 // ---- extraction launches -----------------------------------------------------------------------
 template <int NL, int MODE, int FMT>
@@ -383,7 +611,9 @@ static void launch_extract(kc_ctx *c, const ExtractArgs &a, unsigned ntiles, int
   }
 }
 
-// One block of device-resident input through the extract kernel, in chunks of tiles.
+// One block of device-resident input through extraction, in chunks of tiles.  mode MODE_INSERT feeds this
+// shard's own k-mers to the bucketed path (or the global table once the context is in table mode);
+// MODE_BIN bins by owner shard into the caller's buffer.
 static int run_extract_device(kc_ctx *c, const uint8_t *bases, const uint8_t *quals, const uint64_t *d_offsets, uint64_t nreads,
                               uint64_t total, int mode, int fmt, uint64_t *d_records, uint64_t seg_capacity) {
   if (total == 0) return KC_OK;
@@ -405,13 +635,36 @@ static int run_extract_device(kc_ctx *c, const uint8_t *bases, const uint8_t *qu
   a.records = d_records;
   a.seg_capacity = seg_capacity;
   const uint64_t ntiles_total = (a.align + total + TILE - 1) / TILE;
+  uint64_t buffered = 0;
+  if (mode == MODE_INSERT) {
+    c->started = true;
+    if (bk_active(c)) {
+      int rc = bk_init(c);
+      if (rc) return rc;
+      rc = sync_ctrs(c);
+      if (rc) return rc;
+      if (c->h_ctrs[CTR_BAD_BASE]) return KC_ERR_BAD_BASE;
+      buffered = c->h_ctrs[CTR_INSERTED];
+    }
+  }
   uint64_t t0 = 0;
   while (t0 < ntiles_total) {
-    // a chunk may add at most one new entry per position: keep it within a quarter of the table
-    uint64_t chunk_tiles = std::max<uint64_t>(64, (c->capacity / 4) / TILE);
-    chunk_tiles = std::min<uint64_t>(chunk_tiles, (1ULL << 28) / TILE);
-    uint64_t nt = std::min(chunk_tiles, ntiles_total - t0);
-    if (mode == MODE_INSERT) {
+    const bool bk = (mode == MODE_INSERT) && bk_active(c);
+    uint64_t chunk_tiles;
+    if (bk) {
+      chunk_tiles = (1ULL << 31) / TILE;
+    } else {
+      // a chunk may add at most one new entry per position: keep it within a quarter of the table
+      chunk_tiles = std::max<uint64_t>(64, (c->capacity / 4) / TILE);
+      chunk_tiles = std::min<uint64_t>(chunk_tiles, (1ULL << 28) / TILE);
+    }
+    const uint64_t nt = std::min(chunk_tiles, ntiles_total - t0);
+    if (bk && buffered + nt * TILE > c->bk_capacity) {
+      int rc = bk_drain_to_table(c);  // out of buffer room: this and every later chunk take the table path
+      if (rc) return rc;
+      continue;
+    }
+    if (mode == MODE_INSERT && !bk) {
       int rc = ensure_room(c, nt * TILE);
       if (rc) return rc;
     }
@@ -426,9 +679,16 @@ static int run_extract_device(kc_ctx *c, const uint8_t *bases, const uint8_t *qu
       a.tile_first = c->d_tile_first;
     }
     a.tile0 = t0;
-    launch_extract(c, a, (unsigned)nt, mode, fmt);
+    if (bk) {
+      int rc = launch_l1_reads(c, a, nt, fmt);
+      if (rc) return rc;
+      buffered += nt * TILE;
+    } else {
+      launch_extract(c, a, (unsigned)nt, mode, fmt);
+    }
     HIPCHK(hipGetLastError());
     t0 += nt;
+    if (fmt == FMT_READS && t0 < ntiles_total) HIPCHK(hipStreamSynchronize(c->stream));  // d_tile_first is reused
   }
   return KC_OK;
 }
@@ -467,7 +727,7 @@ static int ensure_stage(kc_ctx *c, size_t bytes, size_t reads, bool need_quals) 
 static int submit_reads_impl(kc_ctx *c, const uint8_t *bases, const uint8_t *quals, const uint64_t *offsets, uint64_t nreads,
                              int on_device, int mode, uint64_t *d_records, uint64_t seg_capacity) {
   if (!c || (nreads && (!bases || !quals || !offsets))) return KC_ERR_INVALID_ARG;
-  if (c->finalized && mode == MODE_INSERT) return KC_ERR_STATE;  // extraction alone never touches the table
+  if ((c->finalized || c->bk_level2) && mode == MODE_INSERT) return KC_ERR_STATE;  // extraction alone never touches the table
   HIPCHK(hipSetDevice(c->cfg.device));
   if (!nreads) return KC_OK;
   if (on_device) {
@@ -521,7 +781,7 @@ extern "C" int kc_submit_reads(kc_ctx *c, const uint8_t *bases, const uint8_t *q
 
 extern "C" int kc_submit_seq_block(kc_ctx *c, const char *seqs, uint64_t len, int on_device) {
   if (!c || (len && !seqs)) return KC_ERR_INVALID_ARG;
-  if (c->finalized) return KC_ERR_STATE;
+  if (c->finalized || c->bk_level2) return KC_ERR_STATE;
   HIPCHK(hipSetDevice(c->cfg.device));
   if (!len) return KC_OK;
   const uint8_t *d = (const uint8_t *)seqs;
@@ -558,15 +818,13 @@ extern "C" int kc_extract_partition(kc_ctx *c, const uint8_t *bases, const uint8
 }
 
 template <int NL>
-static void launch_insert_records(kc_ctx *c, const uint64_t *recs, uint64_t n) {
+static void launch_insert_records(kc_ctx *c, const uint64_t *recs, uint64_t n, uint32_t count_inserted) {
   unsigned nblk = (unsigned)std::min<uint64_t>((n + TPB - 1) / TPB, 256 * 32);
-  hipLaunchKernelGGL(kc_insert_records_kernel<NL>, dim3(nblk), dim3(TPB), 0, c->stream, recs, n, c->table, c->d_ctrs);
+  hipLaunchKernelGGL(kc_insert_records_kernel<NL>, dim3(nblk), dim3(TPB), 0, c->stream, recs, n, c->table, c->d_ctrs, count_inserted);
 }
 
-extern "C" int kc_insert_records(kc_ctx *c, const uint64_t *d_records, uint64_t n) {
-  if (!c || (n && !d_records)) return KC_ERR_INVALID_ARG;
-  if (c->finalized) return KC_ERR_STATE;
-  HIPCHK(hipSetDevice(c->cfg.device));
+// records straight into the global table, growing it as needed
+static int table_insert_records(kc_ctx *c, const uint64_t *d_records, uint64_t n, uint32_t count_inserted) {
   uint64_t done = 0;
   while (done < n) {
     uint64_t m = std::min<uint64_t>(n - done, std::max<uint64_t>(c->capacity / 4, 1u << 18));
@@ -576,16 +834,45 @@ extern "C" int kc_insert_records(kc_ctx *c, const uint64_t *d_records, uint64_t 
     {
       KernelTimer kt(c, KT_INSERT_RECORDS);
       switch (c->nl) {
-        case 1: launch_insert_records<1>(c, p, m); break;
-        case 2: launch_insert_records<2>(c, p, m); break;
-        case 3: launch_insert_records<3>(c, p, m); break;
-        default: launch_insert_records<4>(c, p, m); break;
+        case 1: launch_insert_records<1>(c, p, m, count_inserted); break;
+        case 2: launch_insert_records<2>(c, p, m, count_inserted); break;
+        case 3: launch_insert_records<3>(c, p, m, count_inserted); break;
+        default: launch_insert_records<4>(c, p, m, count_inserted); break;
       }
     }
     HIPCHK(hipGetLastError());
     done += m;
   }
   return KC_OK;
+}
+
+extern "C" int kc_insert_records(kc_ctx *c, const uint64_t *d_records, uint64_t n) {
+  if (!c || (n && !d_records)) return KC_ERR_INVALID_ARG;
+  if (c->finalized || c->bk_level2) return KC_ERR_STATE;
+  HIPCHK(hipSetDevice(c->cfg.device));
+  if (!n) return KC_OK;
+  c->started = true;
+  if (bk_active(c)) {
+    int rc = bk_init(c);
+    if (rc) return rc;
+    rc = sync_ctrs(c);
+    if (rc) return rc;
+    if (c->h_ctrs[CTR_INSERTED] + n > c->bk_capacity) {
+      rc = bk_drain_to_table(c);
+      if (rc) return rc;
+    } else {
+      switch (c->nl) {
+        case 1: rc = launch_l1_records_t<1>(c, d_records, n); break;
+        case 2: rc = launch_l1_records_t<2>(c, d_records, n); break;
+        case 3: rc = launch_l1_records_t<3>(c, d_records, n); break;
+        default: rc = launch_l1_records_t<4>(c, d_records, n); break;
+      }
+      if (rc) return rc;
+      HIPCHK(hipGetLastError());
+      return KC_OK;
+    }
+  }
+  return table_insert_records(c, d_records, n, 1u);
 }
 
 extern "C" int kc_flush(kc_ctx *c) {
@@ -605,6 +892,213 @@ static void launch_finalize(kc_ctx *c) {
                      c->d_out_keys, c->d_out_counts, c->d_out_left, c->d_out_right, c->d_ctrs);
 }
 
+static int alloc_results(kc_ctx *c, uint64_t cap) {
+  free_results(c);
+  if (!cap) cap = 1;
+  HIPCHK(hipMalloc((void **)&c->d_out_keys, cap * c->nl * 8));
+  HIPCHK(hipMalloc((void **)&c->d_out_counts, cap * 2));
+  HIPCHK(hipMalloc((void **)&c->d_out_left, cap));
+  HIPCHK(hipMalloc((void **)&c->d_out_right, cap));
+  c->out_cap = cap;
+  return KC_OK;
+}
+
+// make room for `need` results, keeping the first `keep` already written
+static int grow_results(kc_ctx *c, uint64_t need, uint64_t keep) {
+  if (need <= c->out_cap) return KC_OK;
+  uint64_t *k0 = c->d_out_keys;
+  uint16_t *c0 = c->d_out_counts;
+  uint8_t *l0 = c->d_out_left, *r0 = c->d_out_right;
+  c->d_out_keys = nullptr;
+  c->d_out_counts = nullptr;
+  c->d_out_left = c->d_out_right = nullptr;
+  int rc = alloc_results(c, need);
+  if (!rc && keep) {
+    HIPCHK(hipMemcpyAsync(c->d_out_keys, k0, keep * c->nl * 8, hipMemcpyDeviceToDevice, c->stream));
+    HIPCHK(hipMemcpyAsync(c->d_out_counts, c0, keep * 2, hipMemcpyDeviceToDevice, c->stream));
+    HIPCHK(hipMemcpyAsync(c->d_out_left, l0, keep, hipMemcpyDeviceToDevice, c->stream));
+    HIPCHK(hipMemcpyAsync(c->d_out_right, r0, keep, hipMemcpyDeviceToDevice, c->stream));
+    HIPCHK(hipStreamSynchronize(c->stream));
+  }
+  if (k0) (void)hipFree(k0);
+  if (c0) (void)hipFree(c0);
+  if (l0) (void)hipFree(l0);
+  if (r0) (void)hipFree(r0);
+  return rc;
+}
+
+// S7/S8 over the global table, appended to the result arrays at ctrs[CTR_OUT]
+static int table_finalize_append(kc_ctx *c) {
+  int rc = sync_ctrs(c);
+  if (rc) return rc;
+  const uint64_t entries = c->h_ctrs[CTR_ENTRIES];
+  if (!entries) return KC_OK;
+  rc = grow_results(c, c->h_ctrs[CTR_OUT] + entries, c->h_ctrs[CTR_OUT]);
+  if (rc) return rc;
+  {
+    KernelTimer kt(c, KT_FINALIZE);
+    switch (c->nl) {
+      case 1: launch_finalize<1>(c); break;
+      case 2: launch_finalize<2>(c); break;
+      case 3: launch_finalize<3>(c); break;
+      default: launch_finalize<4>(c); break;
+    }
+  }
+  HIPCHK(hipGetLastError());
+  return KC_OK;
+}
+
+// ---- bucketed path: regions, counting, flagged regions ------------------------------------------
+template <int NL>
+static int bk_level2_t(kc_ctx *c) {
+  auto kern = kc_l2_split_kernel<NL>;
+  int rc = set_dyn_lds(kern, lds_l2());
+  if (rc) return rc;
+  {
+    KernelTimer kt(c, KT_L2_SPLIT);
+    hipLaunchKernelGGL(kern, dim3(std::min<unsigned>(c->gm.P1, (unsigned)c->num_cus)), dim3(WGB), lds_l2(), c->stream, c->gm, c->bb, c->d_cb);
+  }
+  HIPCHK(hipGetLastError());
+  rc = sync_cb(c);
+  if (rc) return rc;
+  const uint64_t n1 = std::min<uint64_t>(c->h_cb[CB_OVF1], c->bb.ovf1_cap);
+  if (n1) {
+    hipLaunchKernelGGL(kc_ovf1_to_regions_kernel<NL>, dim3((unsigned)((n1 + 255) / 256)), dim3(256), 0, c->stream, c->gm, c->bb, n1, c->d_cb);
+    c->num_gpu_calls++;
+    HIPCHK(hipGetLastError());
+  }
+  return KC_OK;
+}
+
+// build the regions from everything buffered (once per reset)
+static int bk_build_regions(kc_ctx *c) {
+  if (c->bk_level2) return KC_OK;
+  int rc = sync_cb(c);
+  if (rc) return rc;
+  if (c->h_cb[CB_FATAL]) {
+    snprintf(g_last_error, sizeof(g_last_error), "k-mer buffer overflow lists exhausted: raise max_kmers_buffered");
+    return KC_ERR_CAPACITY;
+  }
+  switch (c->nl) {
+    case 1: rc = bk_level2_t<1>(c); break;
+    case 2: rc = bk_level2_t<2>(c); break;
+    case 3: rc = bk_level2_t<3>(c); break;
+    default: rc = bk_level2_t<4>(c); break;
+  }
+  if (rc) return rc;
+  c->bk_level2 = true;
+  return KC_OK;
+}
+
+template <int NL, bool DUMP>
+static int bk_count_t(kc_ctx *c, const OutBufs &ob) {
+  auto kern = kc_count_kernel<NL, DUMP>;
+  int rc = set_dyn_lds(kern, sizeof(CountLDS<NL>));
+  if (rc) return rc;
+  const uint64_t R = (uint64_t)c->gm.P1 * c->gm.P2;
+  KernelTimer kt(c, KT_COUNT_REGIONS);
+  hipLaunchKernelGGL(kern, dim3((unsigned)std::min<uint64_t>(R, (uint64_t)c->num_cus)), dim3(WGB), sizeof(CountLDS<NL>), c->stream, c->gm, c->bb,
+                     ob, c->cfg.dmin_thres, c->d_ctrs, c->d_cb);
+  return KC_OK;
+}
+
+static int bk_count(kc_ctx *c, const OutBufs &ob, bool dump) {
+  int rc;
+  if (dump) {
+    switch (c->nl) {
+      case 1: rc = bk_count_t<1, true>(c, ob); break;
+      case 2: rc = bk_count_t<2, true>(c, ob); break;
+      case 3: rc = bk_count_t<3, true>(c, ob); break;
+      default: rc = bk_count_t<4, true>(c, ob); break;
+    }
+  } else {
+    switch (c->nl) {
+      case 1: rc = bk_count_t<1, false>(c, ob); break;
+      case 2: rc = bk_count_t<2, false>(c, ob); break;
+      case 3: rc = bk_count_t<3, false>(c, ob); break;
+      default: rc = bk_count_t<4, false>(c, ob); break;
+    }
+  }
+  if (rc) return rc;
+  HIPCHK(hipGetLastError());
+  return KC_OK;
+}
+
+template <int NL>
+static void launch_flagged_to_table(kc_ctx *c) {
+  const uint64_t R = (uint64_t)c->gm.P1 * c->gm.P2;
+  KernelTimer kt(c, KT_FALLBACK);
+  hipLaunchKernelGGL(kc_flagged_to_table_kernel<NL>, dim3((unsigned)std::min<uint64_t>(R, 65536)), dim3(TPB), 0, c->stream, c->gm, c->bb,
+                     c->table, c->d_ctrs);
+}
+
+// after a count pass: regions that did not fit, and the overflow records, go to the global table (once)
+static int bk_move_flagged(kc_ctx *c) {
+  if (c->bk_flagged) return KC_OK;
+  const uint64_t R = (uint64_t)c->gm.P1 * c->gm.P2;
+  HIPCHK(hipMemsetAsync(c->d_cb + CB_FLAGGED_RECS, 0, 8, c->stream));
+  hipLaunchKernelGGL(kc_sum_flagged_kernel, dim3((unsigned)std::min<uint64_t>((R + 255) / 256, 1024)), dim3(256), 0, c->stream, c->gm, c->bb,
+                     c->d_cb);
+  c->num_gpu_calls++;
+  int rc = sync_cb(c);
+  if (rc) return rc;
+  if (c->h_cb[CB_FATAL]) {
+    snprintf(g_last_error, sizeof(g_last_error), "region overflow list exhausted: raise max_kmers_buffered");
+    return KC_ERR_CAPACITY;
+  }
+  const uint64_t nflag = c->h_cb[CB_FLAGGED_RECS], n2 = std::min<uint64_t>(c->h_cb[CB_OVF2], c->bb.ovf2_cap);
+  if (nflag) {
+    rc = ensure_room(c, nflag + n2);
+    if (rc) return rc;
+    switch (c->nl) {
+      case 1: launch_flagged_to_table<1>(c); break;
+      case 2: launch_flagged_to_table<2>(c); break;
+      case 3: launch_flagged_to_table<3>(c); break;
+      default: launch_flagged_to_table<4>(c); break;
+    }
+    HIPCHK(hipGetLastError());
+  }
+  if (n2) {
+    rc = table_insert_records(c, c->bb.ovf2, n2, 0u);
+    if (rc) return rc;
+  }
+  c->bk_flagged = true;
+  return KC_OK;
+}
+
+static int bk_finalize(kc_ctx *c) {
+  int rc = bk_build_regions(c);
+  if (rc) return rc;
+  rc = sync_ctrs(c);
+  if (rc) return rc;
+  // survivors have count >= 2, so at most half the buffered occurrences; usually far fewer
+  uint64_t cap = std::max<uint64_t>(1u << 16, std::min<uint64_t>(c->h_ctrs[CTR_INSERTED] / 2 + 1,
+                                                                   c->cfg.max_elems ? c->cfg.max_elems / 2 : c->h_ctrs[CTR_INSERTED] / 8 + 1));
+  for (int attempt = 0; attempt < 3; attempt++) {
+    rc = alloc_results(c, cap);
+    if (rc) return rc;
+    HIPCHK(hipMemsetAsync(c->d_ctrs + CTR_OUT, 0, 3 * 8, c->stream));  // OUT, PURGED, SUM_COUNTS
+    HIPCHK(hipMemsetAsync(c->d_cb + CB_ENTRIES, 0, 8, c->stream));
+    OutBufs ob;
+    ob.keys = c->d_out_keys;
+    ob.counts = c->d_out_counts;
+    ob.left = c->d_out_left;
+    ob.right = c->d_out_right;
+    ob.exts = nullptr;
+    ob.cap = c->out_cap;
+    ob.cursor = c->d_ctrs + CTR_OUT;
+    rc = bk_count(c, ob, false);
+    if (rc) return rc;
+    rc = sync_ctrs(c);
+    if (rc) return rc;
+    if (c->h_ctrs[CTR_OUT] <= c->out_cap) break;
+    cap = c->h_ctrs[CTR_OUT];  // the pass only counted past the end: run it again with exactly enough room
+  }
+  rc = bk_move_flagged(c);
+  if (rc) return rc;
+  return table_finalize_append(c);
+}
+
 extern "C" int kc_finalize(kc_ctx *c, kc_result *out) {
   if (!c) return KC_ERR_INVALID_ARG;
   HIPCHK(hipSetDevice(c->cfg.device));
@@ -612,31 +1106,24 @@ extern "C" int kc_finalize(kc_ctx *c, kc_result *out) {
     int rc = sync_ctrs(c);
     if (rc) return rc;
     if (c->h_ctrs[CTR_BAD_BASE]) return KC_ERR_BAD_BASE;
-    const uint64_t entries = c->h_ctrs[CTR_ENTRIES];
-    free_results(c);
-    const uint64_t cap = entries ? entries : 1;
-    HIPCHK(hipMalloc((void **)&c->d_out_keys, cap * c->nl * 8));
-    HIPCHK(hipMalloc((void **)&c->d_out_counts, cap * 2));
-    HIPCHK(hipMalloc((void **)&c->d_out_left, cap));
-    HIPCHK(hipMalloc((void **)&c->d_out_right, cap));
-    c->out_cap = cap;
-    HIPCHK(hipMemsetAsync(c->d_ctrs + CTR_OUT, 0, 3 * 8, c->stream));  // OUT, PURGED, SUM_COUNTS
-    {
-      KernelTimer kt(c, KT_FINALIZE);
-      switch (c->nl) {
-        case 1: launch_finalize<1>(c); break;
-        case 2: launch_finalize<2>(c); break;
-        case 3: launch_finalize<3>(c); break;
-        default: launch_finalize<4>(c); break;
-      }
+    if (c->bk_ready && !c->table_mode) {
+      rc = bk_finalize(c);
+      if (rc) return rc;
+    } else {
+      rc = alloc_results(c, c->h_ctrs[CTR_ENTRIES]);
+      if (rc) return rc;
+      HIPCHK(hipMemsetAsync(c->d_ctrs + CTR_OUT, 0, 3 * 8, c->stream));  // OUT, PURGED, SUM_COUNTS
+      rc = table_finalize_append(c);
+      if (rc) return rc;
     }
-    HIPCHK(hipGetLastError());
     rc = sync_ctrs(c);
+    if (rc) return rc;
+    rc = sync_cb(c);
     if (rc) return rc;
     c->out_n = c->h_ctrs[CTR_OUT];
     c->purged = c->h_ctrs[CTR_PURGED];
     c->sum_counts = c->h_ctrs[CTR_SUM_COUNTS];
-    c->unique_at_finalize = entries;
+    c->unique_at_finalize = c->h_ctrs[CTR_ENTRIES] + c->h_cb[CB_ENTRIES];
     c->finalized = true;
   }
   if (out) {
@@ -664,38 +1151,97 @@ extern "C" int kc_copy_results(kc_ctx *c, uint64_t *keys, uint16_t *counts, uint
   return KC_OK;
 }
 
+// entries of the LDS-counted regions, unfiltered: two passes (size, then write)
+static int bk_dump(kc_ctx *c, uint64_t **dk, uint16_t **dc, uint16_t **de, uint64_t *n_regions) {
+  int rc = bk_build_regions(c);
+  if (rc) return rc;
+  uint64_t cap = 0;
+  *dk = nullptr;
+  *dc = nullptr;
+  *de = nullptr;
+  for (int pass = 0; pass < 2; pass++) {
+    HIPCHK(hipMemsetAsync(c->d_cb + CB_DUMP, 0, 8, c->stream));
+    OutBufs ob;
+    memset(&ob, 0, sizeof(ob));
+    ob.keys = *dk;
+    ob.counts = *dc;
+    ob.exts = *de;
+    ob.cap = cap;
+    ob.cursor = c->d_cb + CB_DUMP;
+    rc = bk_count(c, ob, true);
+    if (rc) return rc;
+    rc = sync_cb(c);
+    if (rc) return rc;
+    if (pass == 0) {
+      cap = c->h_cb[CB_DUMP];
+      if (!cap) break;
+      HIPCHK(hipMalloc((void **)dk, cap * c->nl * 8));
+      HIPCHK(hipMalloc((void **)dc, cap * 2));
+      HIPCHK(hipMalloc((void **)de, cap * 16));
+    }
+  }
+  *n_regions = cap;
+  return bk_move_flagged(c);
+}
+
 extern "C" int kc_dump_table(kc_ctx *c, uint64_t *keys, uint16_t *counts, uint16_t *exts, uint64_t *n_out) {
   if (!c || !n_out) return KC_ERR_INVALID_ARG;
   HIPCHK(hipSetDevice(c->cfg.device));
   int rc = sync_ctrs(c);
   if (rc) return rc;
-  const uint64_t n = c->h_ctrs[CTR_ENTRIES];
-  *n_out = n;
-  if (!keys || !n) return KC_OK;
-  uint64_t *dk = nullptr, *dcur = nullptr;
-  uint16_t *dc = nullptr, *de = nullptr;
-  HIPCHK(hipMalloc((void **)&dk, n * c->nl * 8));
-  HIPCHK(hipMalloc((void **)&dc, n * 2));
-  HIPCHK(hipMalloc((void **)&de, n * 16));
-  HIPCHK(hipMalloc((void **)&dcur, 8));
-  HIPCHK(hipMemsetAsync(dcur, 0, 8, c->stream));
-  const unsigned nblk = (unsigned)((c->capacity + 255) / 256);
-  switch (c->nl) {
-    case 1: hipLaunchKernelGGL(kc_dump_kernel<1>, dim3(nblk), dim3(256), 0, c->stream, c->table, c->capacity, dk, dc, de, dcur); break;
-    case 2: hipLaunchKernelGGL(kc_dump_kernel<2>, dim3(nblk), dim3(256), 0, c->stream, c->table, c->capacity, dk, dc, de, dcur); break;
-    case 3: hipLaunchKernelGGL(kc_dump_kernel<3>, dim3(nblk), dim3(256), 0, c->stream, c->table, c->capacity, dk, dc, de, dcur); break;
-    default: hipLaunchKernelGGL(kc_dump_kernel<4>, dim3(nblk), dim3(256), 0, c->stream, c->table, c->capacity, dk, dc, de, dcur); break;
+  if (c->h_ctrs[CTR_BAD_BASE]) return KC_ERR_BAD_BASE;
+  uint64_t *rk = nullptr;
+  uint16_t *rc16 = nullptr, *re = nullptr;
+  uint64_t nreg = 0;
+  if (c->bk_ready && !c->table_mode) {
+    rc = bk_dump(c, &rk, &rc16, &re, &nreg);
+    if (rc) return rc;
+    rc = sync_ctrs(c);
+    if (rc) return rc;
   }
-  c->num_gpu_calls++;
-  HIPCHK(hipGetLastError());
-  HIPCHK(hipStreamSynchronize(c->stream));
-  HIPCHK(hipMemcpy(keys, dk, n * c->nl * 8, hipMemcpyDeviceToHost));
-  HIPCHK(hipMemcpy(counts, dc, n * 2, hipMemcpyDeviceToHost));
-  HIPCHK(hipMemcpy(exts, de, n * 16, hipMemcpyDeviceToHost));
-  (void)hipFree(dk);
-  (void)hipFree(dc);
-  (void)hipFree(de);
-  (void)hipFree(dcur);
+  const uint64_t ntab = c->h_ctrs[CTR_ENTRIES];
+  const uint64_t n = nreg + ntab;
+  *n_out = n;
+  if (!keys || !n) {
+    if (rk) (void)hipFree(rk);
+    if (rc16) (void)hipFree(rc16);
+    if (re) (void)hipFree(re);
+    return KC_OK;
+  }
+  if (nreg) {
+    HIPCHK(hipMemcpy(keys, rk, nreg * c->nl * 8, hipMemcpyDeviceToHost));
+    HIPCHK(hipMemcpy(counts, rc16, nreg * 2, hipMemcpyDeviceToHost));
+    HIPCHK(hipMemcpy(exts, re, nreg * 16, hipMemcpyDeviceToHost));
+    (void)hipFree(rk);
+    (void)hipFree(rc16);
+    (void)hipFree(re);
+  }
+  if (ntab) {
+    uint64_t *dk = nullptr, *dcur = nullptr;
+    uint16_t *dc = nullptr, *de = nullptr;
+    HIPCHK(hipMalloc((void **)&dk, ntab * c->nl * 8));
+    HIPCHK(hipMalloc((void **)&dc, ntab * 2));
+    HIPCHK(hipMalloc((void **)&de, ntab * 16));
+    HIPCHK(hipMalloc((void **)&dcur, 8));
+    HIPCHK(hipMemsetAsync(dcur, 0, 8, c->stream));
+    const unsigned nblk = (unsigned)((c->capacity + 255) / 256);
+    switch (c->nl) {
+      case 1: hipLaunchKernelGGL(kc_dump_kernel<1>, dim3(nblk), dim3(256), 0, c->stream, c->table, c->capacity, dk, dc, de, dcur); break;
+      case 2: hipLaunchKernelGGL(kc_dump_kernel<2>, dim3(nblk), dim3(256), 0, c->stream, c->table, c->capacity, dk, dc, de, dcur); break;
+      case 3: hipLaunchKernelGGL(kc_dump_kernel<3>, dim3(nblk), dim3(256), 0, c->stream, c->table, c->capacity, dk, dc, de, dcur); break;
+      default: hipLaunchKernelGGL(kc_dump_kernel<4>, dim3(nblk), dim3(256), 0, c->stream, c->table, c->capacity, dk, dc, de, dcur); break;
+    }
+    c->num_gpu_calls++;
+    HIPCHK(hipGetLastError());
+    HIPCHK(hipStreamSynchronize(c->stream));
+    HIPCHK(hipMemcpy(keys + nreg * c->nl, dk, ntab * c->nl * 8, hipMemcpyDeviceToHost));
+    HIPCHK(hipMemcpy(counts + nreg, dc, ntab * 2, hipMemcpyDeviceToHost));
+    HIPCHK(hipMemcpy(exts + nreg * 8, de, ntab * 16, hipMemcpyDeviceToHost));
+    (void)hipFree(dk);
+    (void)hipFree(dc);
+    (void)hipFree(de);
+    (void)hipFree(dcur);
+  }
   return KC_OK;
 }
 
@@ -709,14 +1255,27 @@ extern "C" int kc_get_stats(kc_ctx *c, kc_stats *o) {
   o->num_bases = c->num_bases;
   o->raw_kmers = c->h_ctrs[CTR_RAW_KMERS];
   o->kmers_inserted = c->h_ctrs[CTR_INSERTED];
-  o->num_unique = c->h_ctrs[CTR_ENTRIES];
+  o->num_unique = c->finalized ? c->unique_at_finalize : c->h_ctrs[CTR_ENTRIES];
   o->num_purged = c->purged;
   o->total_kmers = c->out_n;
   o->sum_counts = c->sum_counts;
   o->num_dropped = 0;
   o->capacity = c->capacity;
   o->num_gpu_calls = c->num_gpu_calls;
-  o->table_bytes = c->arena_bytes;
+  o->table_bytes = c->arena_bytes + c->bk_bytes;
+  return KC_OK;
+}
+
+extern "C" int kc_set_tuning(kc_ctx *c, const kc_tuning *t) {
+  if (!c || !t) return KC_ERR_INVALID_ARG;
+  if (c->started) return KC_ERR_STATE;
+  if (t->mode > 1) return KC_ERR_INVALID_ARG;
+  if ((t->p1 && (t->p1 & (t->p1 - 1))) || (t->p2 && (t->p2 & (t->p2 - 1))) || t->p1 > PMAX || t->p2 > PMAX || t->writers > GMAX)
+    return KC_ERR_INVALID_ARG;
+  HIPCHK(hipSetDevice(c->cfg.device));
+  HIPCHK(hipStreamSynchronize(c->stream));
+  c->tuning = *t;
+  bk_free(c);  // the geometry is chosen again at the first submit
   return KC_OK;
 }
 

@@ -1,0 +1,608 @@
+// kc_bucketed.hpp -- the bucketed insert path: the HBM-bound core of libkcount_mi355.
+//
+// Random per-k-mer atomics on an HBM table move a 64-byte sector per 8-byte key and run at the
+// fabric's scattered-atomic rate (the global-table path in kc_kernels.hpp measures ~5 G k-mers/s).
+// Here every k-mer record instead makes two coalesced trips through HBM and is counted in LDS:
+//
+//   level 1  kc_l1_reads_kernel / kc_l1_records_kernel
+//            reads (or records received from other shards) -> canonical k-mer records, multisplit in LDS
+//            by the low hash bits into P1 buckets; every persistent workgroup appends its runs to
+//            segments it alone owns (writer g, bucket b), so no global atomics and no ordering hazards.
+//   level 2  kc_l2_split_kernel
+//            one workgroup per bucket streams the bucket's G segments, multisplits by the next hash bits
+//            into P2 regions and appends to region arrays it alone owns.
+//   count    kc_count_kernel
+//            one workgroup per region: an open-addressed (linear probe) table of S slots lives in LDS
+//            -- the "probe window" of the region; records are streamed once, keys claimed by LDS
+//            compare-and-swap, count / extension votes bumped by LDS atomics; then S7 vote, S8 purge
+//            and a ballot/prefix compaction straight into the dense result arrays.
+//
+// A region that does not fit (too many records for its array, or more distinct k-mers than LDS slots)
+// is flagged and handled, whole, by the global-table kernels of kc_kernels.hpp, so every k-mer lives in
+// exactly one structure and nothing is ever dropped.
+//
+// Replaces gpu_insert_supermer_block / gpu_insert_kmer / gpu_purge_invalid / gpu_compact_ht of the
+// reference (src/kcount/kcount-gpu/gpu_hash_table.cpp:205-268,357-475) with CPU-backend semantics.
+#pragma once
+#include "kc_kernels.hpp"
+
+namespace kc {
+
+constexpr int WGB = 1024;        // threads per workgroup in this file (16 waves: one workgroup per CU)
+constexpr int QUARTERS = WGB / TPB;
+constexpr int PMAX = 1024;       // max fan-out of either level
+constexpr int GMAX = 1024;       // max level-1 writers
+
+// records held per thread and round, by key width (bounds registers and the LDS staging area)
+// RPOS: when the records come from memory; RPOS_READS: when each is cut out of a staged tile (more live registers)
+template <int NL> struct Rnd {
+  static constexpr int RPOS = NL == 1 ? 16 : NL == 2 ? 8 : 4;
+  static constexpr int RPOS_READS = NL <= 2 ? 8 : 4;
+};
+constexpr int STAGE_BYTES = 131072;  // sorted staging: WGB * RPOS * NL * 8 <= 128 KiB for every NL
+
+struct Geom {
+  uint32_t G, P1, P2, S;     // writers, fan-outs (powers of two), LDS slots per region
+  uint32_t log2P1, log2P2;
+  uint64_t C1, C2;           // capacity in records of one (writer,bucket) segment / one region array
+};
+
+struct BucketBufs {
+  uint64_t *rec1;    // [G][P1][C1] records
+  uint32_t *cnt1;    // [G][P1]
+  uint64_t *rec2;    // [P1*P2][C2]
+  uint32_t *cnt2;    // [P1*P2]
+  uint32_t *flag;    // [P1*P2]: 0 fine, 1 array overflowed (level 2), 2 more distinct k-mers than slots (count)
+  uint64_t *ovf1;    // level-1 overflow: records without a home segment
+  uint64_t *ovf2;    // level-2 overflow: records of flagged regions
+  uint64_t ovf1_cap, ovf2_cap;
+};
+
+enum {  // more counters (continue kc_kernels.hpp's list inside the CTR_BIN0.. block is not possible: own block)
+  CB_OVF1 = 0, CB_OVF2, CB_FATAL, CB_FLAGGED_RECS, CB_DUMP, CB_ENTRIES, CB_COUNT = 16
+};
+
+__device__ __forceinline__ uint32_t hash_b1(uint64_t h, const Geom &g) { return (uint32_t)h & (g.P1 - 1); }
+__device__ __forceinline__ uint32_t hash_b2(uint64_t h, const Geom &g) { return (uint32_t)(h >> g.log2P1) & (g.P2 - 1); }
+__device__ __forceinline__ uint32_t hash_slot(uint64_t h, uint32_t S) {
+  return (uint32_t)(((uint64_t)(uint32_t)(h >> 21) * (uint64_t)S) >> 32);
+}
+
+template <int NL>
+__device__ __forceinline__ uint64_t rec_hash(const uint64_t (&rec)[NL]) {
+  uint64_t key[NL];
+#pragma unroll
+  for (int j = 0; j < NL; j++) key[j] = rec[j];
+  key[NL - 1] &= ~KC_EXT_MASK;
+  return kc_hash<NL>(key);
+}
+
+// ---- workgroup exclusive scan over WGB values --------------------------------------------------
+struct ScanLDS {
+  uint32_t wsum[32];
+  uint32_t wpre[32];
+  uint32_t total;
+};
+
+__device__ __forceinline__ uint32_t wave_incl_scan(uint32_t v) {
+#pragma unroll
+  for (int o = 1; o < 64; o <<= 1) {
+    uint32_t n = __shfl_up(v, o);
+    if ((int)lane_id() >= o) v += n;
+  }
+  return v;
+}
+
+// every thread of the workgroup calls this; returns the exclusive prefix of v, total in S.total (valid after return)
+__device__ __forceinline__ uint32_t block_excl_scan(uint32_t v, ScanLDS &S) {
+  const int tid = threadIdx.x, wave = tid >> 6;
+  const uint32_t incl = wave_incl_scan(v);
+  if (lane_id() == 63) S.wsum[wave] = incl;
+  __syncthreads();
+  if (tid < 64) {
+    const uint32_t w = (tid < WGB / 64) ? S.wsum[tid] : 0;
+    const uint32_t wi = wave_incl_scan(w);
+    if (tid < 32) S.wpre[tid] = wi - w;
+    if (tid == WGB / 64 - 1) S.total = wi;
+  }
+  __syncthreads();
+  return incl - v + S.wpre[wave];
+}
+
+// ---- multisplit of one round of records held in registers ---------------------------------------
+// LDS working set shared by both split kernels
+struct SplitLDS {
+  uint32_t hist[2][PMAX];  // per-bucket counts of this round (double-buffered); becomes "fit" after the scan
+  uint32_t offs[PMAX];     // exclusive prefix: where the bucket's run starts in the sorted staging
+  uint32_t dbase[PMAX];    // where the run goes in the bucket's destination array
+  uint32_t cur[PMAX];      // fill of each destination array owned by this workgroup
+  ScanLDS scan;
+};
+
+// Phase 2-4 of a round: scan, reserve, scatter to LDS, copy out.  The caller has already bumped
+// hist[buf] with LDS atomics (bucket | rank<<10 in br[], ~0 for "no record") and hit a barrier.
+//   dest(b)  -> pointer to the destination array of bucket b (records), capacity cap
+//   bucket_of(hash) recomputes a record's bucket during copy-out
+template <int NL, int R, class DestFn, class BucketFn, class OvfFn>
+__device__ __forceinline__ void split_round(SplitLDS &L, uint64_t *sorted, int buf, uint32_t P, const uint64_t (&rec)[R][NL],
+                                            const uint32_t (&br)[R], uint64_t cap, DestFn dest, BucketFn bucket_of, OvfFn overflow) {
+  const int tid = threadIdx.x;
+  uint32_t *H = L.hist[buf];
+  const uint32_t v = ((uint32_t)tid < P) ? H[tid] : 0u;
+  const uint32_t excl = block_excl_scan(v, L.scan);
+  if ((uint32_t)tid < P) {
+    L.offs[tid] = excl;
+    const uint32_t base = L.cur[tid];
+    const uint64_t room = cap - (uint64_t)base;
+    const uint32_t fit = (uint64_t)v <= room ? v : (uint32_t)room;
+    L.dbase[tid] = base;
+    H[tid] = fit;
+    L.cur[tid] = base + fit;
+    L.hist[buf ^ 1][tid] = 0;  // next round's histogram
+  }
+  __syncthreads();
+  const uint32_t total = L.scan.total;
+#pragma unroll
+  for (int j = 0; j < R; j++) {
+    if (br[j] != ~0u) {
+      const uint32_t b = br[j] & (PMAX - 1), rank = br[j] >> 10;
+      const uint32_t pos = L.offs[b] + rank;
+#pragma unroll
+      for (int w = 0; w < NL; w++) sorted[(size_t)pos * NL + w] = rec[j][w];
+    }
+  }
+  __syncthreads();
+  for (uint32_t i = tid; i < total; i += WGB) {
+    uint64_t r[NL];
+#pragma unroll
+    for (int w = 0; w < NL; w++) r[w] = sorted[(size_t)i * NL + w];
+    const uint32_t b = bucket_of(rec_hash<NL>(r));
+    const uint32_t j = i - L.offs[b];
+    if (j < H[b]) {
+      uint64_t *d = dest(b) + ((size_t)L.dbase[b] + j) * NL;
+#pragma unroll
+      for (int w = 0; w < NL; w++) d[w] = r[w];
+    } else {
+      overflow(b, r);
+    }
+  }
+  __syncthreads();
+}
+
+// ---- level 1 from reads ---------------------------------------------------------------------------
+struct L1LDS {
+  TileLDS tile[QUARTERS];
+  SplitLDS sp;
+};
+
+template <int NL, int FMT>
+__global__ __launch_bounds__(WGB) void kc_l1_reads_kernel(ExtractArgs a, Geom gm, BucketBufs bb, uint64_t ntiles, uint32_t rot,
+                                                          uint64_t *ctrs, uint64_t *cb) {
+  extern __shared__ __align__(16) uint8_t smem[];
+  L1LDS &L = *reinterpret_cast<L1LDS *>(smem);
+  uint64_t *sorted = reinterpret_cast<uint64_t *>(smem + ((sizeof(L1LDS) + 15) & ~size_t(15)));
+  constexpr int RPOS = Rnd<NL>::RPOS_READS;
+  const int tid = threadIdx.x, q = tid >> 8, qt = tid & (TPB - 1);
+  // writer id: launches rotate their first writer (rot) so that many small submits still spread evenly
+  const uint32_t g = (blockIdx.x + rot) % gm.G, P1 = gm.P1;
+  if ((uint32_t)tid < P1) {
+    L.sp.cur[tid] = bb.cnt1[(size_t)g * P1 + tid];
+    L.sp.hist[0][tid] = 0;
+    L.sp.hist[1][tid] = 0;
+  }
+  __syncthreads();
+  const int64_t lo = a.align, hi = (int64_t)a.align + (int64_t)a.total;
+  const uint64_t nsuper = (ntiles + QUARTERS - 1) / QUARTERS;
+  uint32_t n_ins = 0;
+  int buf = 0;
+  uint64_t *seg0 = bb.rec1 + (size_t)g * P1 * gm.C1 * NL;
+  for (uint64_t st = blockIdx.x; st < nsuper; st += gridDim.x) {
+    const uint64_t tile = st * QUARTERS + q;
+    const bool active = tile < ntiles;
+    const int64_t T0 = (int64_t)(a.tile0 + tile) * TILE;
+    stage_tile<FMT>(L.tile[q], a, T0, ctrs, qt, (active && FMT == FMT_READS) ? a.tile_first[tile] : 0, active);
+#pragma unroll 1
+    for (int round = 0; round < PPT / RPOS; round++) {
+      uint64_t rec[RPOS][NL];
+      uint32_t br[RPOS];
+#pragma unroll
+      for (int j = 0; j < RPOS; j++) {
+        const int off = (round * RPOS + j) * TPB + qt;
+        const int64_t x = T0 + off;
+        uint64_t h = 0;
+        bool valid = active && (x > lo) && (x + a.k < hi) && tile_kmer<NL>(L.tile[q], PRE + off, a.k, rec[j], h);
+        if (valid && a.rank_n > 1) valid = kc_owner_of_hash(h, a.rank_n) == a.rank_me;
+        br[j] = ~0u;
+        if (valid) {
+          const uint32_t b = hash_b1(h, gm);
+          const uint32_t rank = atomicAdd(&L.sp.hist[buf][b], 1u);
+          br[j] = b | (rank << 10);
+          n_ins++;
+        }
+      }
+      __syncthreads();
+      split_round<NL, RPOS>(
+          L.sp, sorted, buf, P1, rec, br, gm.C1, [&](uint32_t b) { return seg0 + (size_t)b * gm.C1 * NL; },
+          [&](uint64_t h) { return hash_b1(h, gm); },
+          [&](uint32_t, const uint64_t (&r)[NL]) {
+            const uint64_t o = atomicAdd((unsigned long long *)&cb[CB_OVF1], 1ULL);
+            if (o < bb.ovf1_cap) {
+#pragma unroll
+              for (int w = 0; w < NL; w++) bb.ovf1[o * NL + w] = r[w];
+            } else {
+              cb[CB_FATAL] = 1;
+            }
+          });
+      buf ^= 1;
+    }
+  }
+  if ((uint32_t)tid < P1) bb.cnt1[(size_t)g * P1 + tid] = L.sp.cur[tid];
+  for (int o = 32; o > 0; o >>= 1) n_ins += __shfl_down(n_ins, o);
+  if (lane_id() == 0 && n_ins) atomicAdd((unsigned long long *)&ctrs[CTR_INSERTED], (unsigned long long)n_ins);
+}
+
+// ---- level 1 from records (receiver side of the shard exchange) -------------------------------------
+struct L1RLDS {
+  SplitLDS sp;
+};
+
+template <int NL>
+__global__ __launch_bounds__(WGB) void kc_l1_records_kernel(const uint64_t *recs, uint64_t n, Geom gm, BucketBufs bb, uint32_t rot,
+                                                            uint64_t *ctrs, uint64_t *cb) {
+  extern __shared__ __align__(16) uint8_t smem[];
+  L1RLDS &L = *reinterpret_cast<L1RLDS *>(smem);
+  uint64_t *sorted = reinterpret_cast<uint64_t *>(smem + ((sizeof(L1RLDS) + 15) & ~size_t(15)));
+  constexpr int RPOS = Rnd<NL>::RPOS;
+  const int tid = threadIdx.x;
+  const uint32_t g = (blockIdx.x + rot) % gm.G, P1 = gm.P1;
+  if ((uint32_t)tid < P1) {
+    L.sp.cur[tid] = bb.cnt1[(size_t)g * P1 + tid];
+    L.sp.hist[0][tid] = 0;
+    L.sp.hist[1][tid] = 0;
+  }
+  __syncthreads();
+  uint64_t *seg0 = bb.rec1 + (size_t)g * P1 * gm.C1 * NL;
+  const uint64_t per_round = (uint64_t)WGB * RPOS;
+  const uint64_t nrounds = (n + per_round - 1) / per_round;
+  uint32_t n_ins = 0;
+  int buf = 0;
+  for (uint64_t rd = blockIdx.x; rd < nrounds; rd += gridDim.x) {
+    uint64_t rec[RPOS][NL];
+    uint32_t br[RPOS];
+#pragma unroll
+    for (int j = 0; j < RPOS; j++) {
+      const uint64_t i = rd * per_round + (uint64_t)j * WGB + tid;
+      br[j] = ~0u;
+      if (i < n) {
+#pragma unroll
+        for (int w = 0; w < NL; w++) rec[j][w] = recs[i * NL + w];
+        const uint32_t b = hash_b1(rec_hash<NL>(rec[j]), gm);
+        const uint32_t rank = atomicAdd(&L.sp.hist[buf][b], 1u);
+        br[j] = b | (rank << 10);
+        n_ins++;
+      }
+    }
+    __syncthreads();
+    split_round<NL, RPOS>(
+        L.sp, sorted, buf, P1, rec, br, gm.C1, [&](uint32_t b) { return seg0 + (size_t)b * gm.C1 * NL; },
+        [&](uint64_t h) { return hash_b1(h, gm); },
+        [&](uint32_t, const uint64_t (&r)[NL]) {
+          const uint64_t o = atomicAdd((unsigned long long *)&cb[CB_OVF1], 1ULL);
+          if (o < bb.ovf1_cap) {
+#pragma unroll
+            for (int w = 0; w < NL; w++) bb.ovf1[o * NL + w] = r[w];
+          } else {
+            cb[CB_FATAL] = 1;
+          }
+        });
+    buf ^= 1;
+  }
+  if ((uint32_t)tid < P1) bb.cnt1[(size_t)g * P1 + tid] = L.sp.cur[tid];
+  for (int o = 32; o > 0; o >>= 1) n_ins += __shfl_down(n_ins, o);
+  if (lane_id() == 0 && n_ins) atomicAdd((unsigned long long *)&ctrs[CTR_INSERTED], (unsigned long long)n_ins);
+}
+
+// ---- level 2 ------------------------------------------------------------------------------------------
+struct L2LDS {
+  SplitLDS sp;
+  uint32_t pre[GMAX + 1];  // prefix of the bucket's G segment lengths
+};
+
+template <int NL>
+__global__ __launch_bounds__(WGB) void kc_l2_split_kernel(Geom gm, BucketBufs bb, uint64_t *cb) {
+  extern __shared__ __align__(16) uint8_t smem[];
+  L2LDS &L = *reinterpret_cast<L2LDS *>(smem);
+  uint64_t *sorted = reinterpret_cast<uint64_t *>(smem + ((sizeof(L2LDS) + 15) & ~size_t(15)));
+  constexpr int RPOS = Rnd<NL>::RPOS;
+  const int tid = threadIdx.x;
+  const uint32_t P1 = gm.P1, P2 = gm.P2, G = gm.G;
+  for (uint32_t b1 = blockIdx.x; b1 < P1; b1 += gridDim.x) {
+    // prefix over the G segments of this bucket
+    {
+      const uint32_t v = ((uint32_t)tid < G) ? bb.cnt1[(size_t)tid * P1 + b1] : 0u;
+      const uint32_t e = block_excl_scan(v, L.sp.scan);
+      if ((uint32_t)tid < G) L.pre[tid] = e;
+      if (tid == 0) L.pre[G] = L.sp.scan.total;
+      if ((uint32_t)tid < P2) {
+        L.sp.cur[tid] = 0;
+        L.sp.hist[0][tid] = 0;
+        L.sp.hist[1][tid] = 0;
+      }
+    }
+    __syncthreads();
+    const uint32_t n = L.pre[G];
+    uint64_t *reg0 = bb.rec2 + (size_t)b1 * P2 * gm.C2 * NL;
+    const uint32_t per_round = WGB * RPOS;
+    uint32_t p = 0;  // segment cursor of this thread (its indices only grow)
+    int buf = 0;
+    for (uint32_t v0 = 0; v0 < n; v0 += per_round) {
+      uint64_t rec[RPOS][NL];
+      uint32_t br[RPOS];
+#pragma unroll
+      for (int j = 0; j < RPOS; j++) {
+        const uint32_t e = v0 + (uint32_t)j * WGB + tid;
+        br[j] = ~0u;
+        if (e < n) {
+          while (e >= L.pre[p + 1]) p++;
+          const uint64_t *src = bb.rec1 + (((size_t)p * P1 + b1) * gm.C1 + (e - L.pre[p])) * NL;
+#pragma unroll
+          for (int w = 0; w < NL; w++) rec[j][w] = src[w];
+          const uint32_t b = hash_b2(rec_hash<NL>(rec[j]), gm);
+          const uint32_t rank = atomicAdd(&L.sp.hist[buf][b], 1u);
+          br[j] = b | (rank << 10);
+        }
+      }
+      __syncthreads();
+      split_round<NL, RPOS>(
+          L.sp, sorted, buf, P2, rec, br, gm.C2, [&](uint32_t b) { return reg0 + (size_t)b * gm.C2 * NL; },
+          [&](uint64_t h) { return hash_b2(h, gm); },
+          [&](uint32_t b, const uint64_t (&r)[NL]) {
+            bb.flag[(size_t)b1 * P2 + b] = 1;
+            const uint64_t o = atomicAdd((unsigned long long *)&cb[CB_OVF2], 1ULL);
+            if (o < bb.ovf2_cap) {
+#pragma unroll
+              for (int w = 0; w < NL; w++) bb.ovf2[o * NL + w] = r[w];
+            } else {
+              cb[CB_FATAL] = 1;
+            }
+          });
+      buf ^= 1;
+    }
+    if ((uint32_t)tid < P2) bb.cnt2[(size_t)b1 * P2 + tid] = L.sp.cur[tid];
+    __syncthreads();
+  }
+}
+
+// level-1 overflow records find their region with one atomic each (rare path)
+template <int NL>
+__global__ void kc_ovf1_to_regions_kernel(Geom gm, BucketBufs bb, uint64_t n, uint64_t *cb) {
+  const uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= n) return;
+  uint64_t r[NL];
+  for (int w = 0; w < NL; w++) r[w] = bb.ovf1[i * NL + w];
+  const uint64_t h = rec_hash<NL>(r);
+  const size_t reg = (size_t)hash_b1(h, gm) * gm.P2 + hash_b2(h, gm);
+  const uint32_t idx = atomicAdd(&bb.cnt2[reg], 1u);
+  if (idx < gm.C2) {
+    uint64_t *d = bb.rec2 + (reg * gm.C2 + idx) * NL;
+    for (int w = 0; w < NL; w++) d[w] = r[w];
+  } else {
+    atomicSub(&bb.cnt2[reg], 1u);  // cnt2 stays the number of records stored in the array
+    bb.flag[reg] = 1;
+    const uint64_t o = atomicAdd((unsigned long long *)&cb[CB_OVF2], 1ULL);
+    if (o < bb.ovf2_cap) {
+      for (int w = 0; w < NL; w++) bb.ovf2[o * NL + w] = r[w];
+    } else {
+      cb[CB_FATAL] = 1;
+    }
+  }
+}
+
+// ---- count: the LDS probe window ---------------------------------------------------------------------
+// LDS image of one region, structure-of-arrays so that neighbouring slots sit in neighbouring banks.
+template <int NL>
+struct CountLDS {
+  static constexpr uint32_t SMAX = (147456 - 64) / (8 * NL + 36);
+  uint64_t keys[SMAX * NL];  // word w of slot s at keys[w*SMAX + s]; the LAST word is the claim word
+  uint32_t cnt[SMAX];
+  uint32_t ext[8 * SMAX];    // ext[e*SMAX + s]
+  uint32_t nout, nent, fail, gbase_lo, gbase_hi;
+  unsigned long long sum;
+};
+
+struct OutBufs {
+  uint64_t *keys;
+  uint16_t *counts;
+  uint8_t *left, *right;
+  uint16_t *exts;    // DUMP only: 8 per entry
+  uint64_t cap;
+  uint64_t *cursor;  // global append position (results: &ctrs[CTR_OUT])
+};
+
+template <int NL>
+__device__ __forceinline__ void lds_insert(CountLDS<NL> &T, uint32_t S, const uint64_t (&rec)[NL]) {
+  constexpr uint32_t SM = CountLDS<NL>::SMAX;
+  uint64_t key[NL];
+#pragma unroll
+  for (int j = 0; j < NL; j++) key[j] = rec[j];
+  const uint32_t le = (uint32_t)(rec[NL - 1] & 7u), re = (uint32_t)((rec[NL - 1] >> 3) & 7u);
+  key[NL - 1] &= ~KC_EXT_MASK;
+  uint32_t s = hash_slot(kc_hash<NL>(key), S);
+  unsigned long long *claim = (unsigned long long *)&T.keys[(NL - 1) * SM];
+  uint32_t probes = 0;
+  for (;;) {
+    unsigned long long cur = __hip_atomic_load(&claim[s], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+    if (cur == KEY_EMPTY) {
+      cur = atomicCAS(&claim[s], (unsigned long long)KEY_EMPTY, (unsigned long long)(NL == 1 ? key[0] : KEY_BUSY));
+      if (cur == KEY_EMPTY) {
+        if (NL > 1) {
+#pragma unroll
+          for (int j = 0; j < NL - 1; j++) T.keys[j * SM + s] = key[j];
+          __threadfence_block();
+          atomicExch(&claim[s], (unsigned long long)key[NL - 1]);
+        }
+        atomicAdd(&T.nent, 1u);
+        break;
+      }
+    }
+    if (NL > 1 && cur == KEY_BUSY) continue;  // its owner publishes within this loop trip of its wave
+    if (cur == key[NL - 1]) {
+      bool same = true;
+      if (NL > 1) {
+#pragma unroll
+        for (int j = 0; j < NL - 1; j++) same &= (T.keys[j * SM + s] == key[j]);
+      }
+      if (same) break;
+    }
+    s = (s + 1 == S) ? 0 : s + 1;
+    if (++probes >= S) {  // every slot holds some other k-mer
+      T.fail = 1;
+      return;
+    }
+  }
+  atomicAdd(&T.cnt[s], 1u);
+  if (le < 4u) atomicAdd(&T.ext[le * SM + s], 1u);
+  if (re < 4u) atomicAdd(&T.ext[(4 + re) * SM + s], 1u);
+}
+
+// DUMP = false: S7 vote + S8 purge, survivors to the result arrays.  DUMP = true: every entry with its raw
+// (clipped) counters, for tests of S5/S6; no statistics are touched.
+template <int NL, bool DUMP>
+__global__ __launch_bounds__(WGB) void kc_count_kernel(Geom gm, BucketBufs bb, OutBufs out, int dmin_thres, uint64_t *ctrs,
+                                                       uint64_t *cb) {
+  extern __shared__ __align__(16) uint8_t smem[];
+  CountLDS<NL> &T = *reinterpret_cast<CountLDS<NL> *>(smem);
+  constexpr uint32_t SM = CountLDS<NL>::SMAX;
+  const int tid = threadIdx.x;
+  const uint32_t S = gm.S;
+  const size_t R = (size_t)gm.P1 * gm.P2;
+  for (size_t r = blockIdx.x; r < R; r += gridDim.x) {
+    const uint32_t n = bb.cnt2[r];
+    if (n == 0 || bb.flag[r]) continue;  // uniform across the workgroup
+    for (uint32_t s = tid; s < S; s += WGB) {
+#pragma unroll
+      for (int w = 0; w < NL; w++) T.keys[w * SM + s] = KEY_EMPTY;
+      T.cnt[s] = 0;
+#pragma unroll
+      for (int e = 0; e < 8; e++) T.ext[e * SM + s] = 0;
+    }
+    if (tid == 0) {
+      T.nout = 0;
+      T.nent = 0;
+      T.fail = 0;
+      T.sum = 0;
+    }
+    __syncthreads();
+    const uint64_t *src = bb.rec2 + r * gm.C2 * NL;
+    for (uint32_t i = tid; i < n; i += WGB) {
+      uint64_t rec[NL];
+#pragma unroll
+      for (int w = 0; w < NL; w++) rec[w] = src[(size_t)i * NL + w];
+      lds_insert<NL>(T, S, rec);
+    }
+    __syncthreads();
+    if (T.fail) {  // more distinct k-mers than slots: the whole region goes to the global table instead
+      if (tid == 0) bb.flag[r] = 2;
+      __syncthreads();
+      continue;
+    }
+    // S7 vote + S8 purge; survivors get a rank
+    for (uint32_t s = tid; s < S; s += WGB) {
+      uint32_t packed = ~0u;
+      if (T.keys[(NL - 1) * SM + s] != KEY_EMPTY) {
+        const uint32_t count = min(T.cnt[s], KC_COUNT_MAX);
+        if (DUMP) {
+          packed = count | (atomicAdd(&T.nout, 1u) << 20);
+        } else if (count >= 2) {
+          uint32_t lc[4], rc[4];
+#pragma unroll
+          for (int e = 0; e < 4; e++) {
+            lc[e] = min(T.ext[e * SM + s], KC_COUNT_MAX);
+            rc[e] = min(T.ext[(4 + e) * SM + s], KC_COUNT_MAX);
+          }
+          const uint32_t l = vote_ext(lc, count, dmin_thres), rr = vote_ext(rc, count, dmin_thres);
+          if (l < 4u && rr < 4u) {
+            const uint32_t rank = atomicAdd(&T.nout, 1u);
+            packed = count | (l << 16) | (rr << 18) | (rank << 20);
+            atomicAdd(&T.sum, (unsigned long long)count);
+          }
+        }
+      }
+      T.cnt[s] = packed;
+    }
+    __syncthreads();
+    if (tid == 0) {
+      const uint64_t gb = atomicAdd((unsigned long long *)out.cursor, (unsigned long long)T.nout);
+      T.gbase_lo = (uint32_t)gb;
+      T.gbase_hi = (uint32_t)(gb >> 32);
+      if (!DUMP) {
+        atomicAdd((unsigned long long *)&cb[CB_ENTRIES], (unsigned long long)T.nent);
+        atomicAdd((unsigned long long *)&ctrs[CTR_PURGED], (unsigned long long)(T.nent - T.nout));
+        atomicAdd((unsigned long long *)&ctrs[CTR_SUM_COUNTS], T.sum);
+      }
+    }
+    __syncthreads();
+    const uint64_t gbase = ((uint64_t)T.gbase_hi << 32) | T.gbase_lo;
+    for (uint32_t s = tid; s < S; s += WGB) {
+      const uint32_t p = T.cnt[s];
+      if (p == ~0u) continue;
+      const uint64_t o = gbase + (p >> 20);
+      if (o < out.cap) {  // beyond the arrays: the host sees the cursor past cap and re-runs with more room
+#pragma unroll
+        for (int w = 0; w < NL; w++) out.keys[o * NL + w] = T.keys[w * SM + s];
+        out.counts[o] = (uint16_t)(p & 0xFFFFu);
+        if (DUMP) {
+#pragma unroll
+          for (int e = 0; e < 8; e++) out.exts[o * 8 + e] = (uint16_t)min(T.ext[e * SM + s], KC_COUNT_MAX);
+        } else {
+          out.left[o] = (uint8_t)("ACGT"[(p >> 16) & 3u]);
+          out.right[o] = (uint8_t)("ACGT"[(p >> 18) & 3u]);
+        }
+      }
+    }
+    __syncthreads();
+  }
+}
+
+// records of flagged regions go to the global table (kc_kernels.hpp): one workgroup per flagged region at a time
+template <int NL>
+__global__ __launch_bounds__(TPB) void kc_flagged_to_table_kernel(Geom gm, BucketBufs bb, Table t, uint64_t *ctrs) {
+  const size_t R = (size_t)gm.P1 * gm.P2;
+  for (size_t r = blockIdx.x; r < R; r += gridDim.x) {
+    if (!bb.flag[r]) continue;
+    const uint32_t n = bb.cnt2[r];
+    const uint64_t *src = bb.rec2 + r * gm.C2 * NL;
+    for (uint32_t i = threadIdx.x; i < n; i += TPB) {
+      uint64_t rec[NL];
+      for (int w = 0; w < NL; w++) rec[w] = src[(size_t)i * NL + w];
+      table_insert<NL>(t, rec, ctrs);
+    }
+  }
+}
+
+// every buffered level-1 record goes to the global table (the context ran out of buffer room and
+// switches to the table path for good)
+template <int NL>
+__global__ __launch_bounds__(TPB) void kc_l1_to_table_kernel(Geom gm, BucketBufs bb, Table t, uint64_t *ctrs) {
+  const size_t nseg = (size_t)gm.G * gm.P1;
+  for (size_t sgi = blockIdx.x; sgi < nseg; sgi += gridDim.x) {
+    const uint32_t n = bb.cnt1[sgi];
+    const uint64_t *src = bb.rec1 + sgi * gm.C1 * NL;
+    for (uint32_t i = threadIdx.x; i < n; i += TPB) {
+      uint64_t rec[NL];
+      for (int w = 0; w < NL; w++) rec[w] = src[(size_t)i * NL + w];
+      table_insert<NL>(t, rec, ctrs);
+    }
+  }
+}
+
+__global__ void kc_sum_flagged_kernel(Geom gm, BucketBufs bb, uint64_t *cb) {
+  const size_t R = (size_t)gm.P1 * gm.P2;
+  unsigned long long acc = 0;
+  for (size_t r = (size_t)blockIdx.x * blockDim.x + threadIdx.x; r < R; r += (size_t)gridDim.x * blockDim.x)
+    if (bb.flag[r]) acc += bb.cnt2[r];
+  for (int o = 32; o > 0; o >>= 1) acc += __shfl_down(acc, o);
+  if (lane_id() == 0 && acc) atomicAdd((unsigned long long *)&cb[CB_FLAGGED_RECS], acc);
+}
+
+}  // namespace kc

@@ -64,12 +64,17 @@ KC_HD uint64_t kc_word_mask(int k, int j) {
 template <int NL>
 KC_HD void kc_revcomp(const uint64_t (&w)[NL], int k, uint64_t (&out)[NL]) {
   const int ll = (k + 31) / 32;  // words that hold bases
+  // t[i] = rc(w[ll-1-i]) for i < ll; written with compile-time indices only (a run-time index would
+  // push the arrays to scratch memory)
   uint64_t t[NL];
 #pragma unroll
-  for (int j = 0; j < NL; j++) t[j] = 0;
+  for (int i = 0; i < NL; i++) {
+    uint64_t v = 0;
 #pragma unroll
-  for (int j = 0; j < NL; j++)
-    if (j < ll) t[ll - 1 - j] = kc_rc_word(w[j]);
+    for (int j = 0; j < NL; j++)
+      if (j == ll - 1 - i) v = kc_rc_word(w[j]);
+    t[i] = v;
+  }
   const int sh = 64 * ll - 2 * k;  // 0..62
   if (sh) {
 #pragma unroll

@@ -160,10 +160,15 @@ __device__ __forceinline__ bool in_bitmap(uint32_t c, uint32_t bm) { return ((c 
 // Stage the tile.  Aligned coordinate x = byte index from the 16-byte aligned base address; local
 // position lp = x - (T0 - PRE).
 template <int FMT>
-__device__ __forceinline__ void stage_tile(TileLDS &L, const ExtractArgs &a, int64_t T0, uint64_t *ctrs) {
-  const int tid = threadIdx.x;
+__device__ __forceinline__ void stage_tile(TileLDS &L, const ExtractArgs &a, int64_t T0, uint64_t *ctrs, int tid, uint64_t tile_first_read,
+                                           bool active) {
+  // tid: 0..TPB-1 within the TPB threads that share this tile; every thread of the workgroup reaches both barriers
   for (int i = tid; i < NWORD + 1; i += TPB) L.gap[i] = 0;
   __syncthreads();
+  if (!active) {
+    __syncthreads();
+    return;
+  }
   const int64_t lo = a.align, hi = (int64_t)a.align + (int64_t)a.total;  // real data is [lo, hi)
   bool bad = false;
   for (int g = tid; g < NGROUP; g += TPB) {
@@ -219,7 +224,7 @@ __device__ __forceinline__ void stage_tile(TileLDS &L, const ExtractArgs &a, int
   if (FMT == FMT_READS) {
     // boundaries from the read offsets (the end of the data is offsets[nreads])
     const int64_t first = T0, last = T0 + TILE + a.k;  // gaps that any window of this tile can contain
-    for (uint64_t r = a.tile_first[blockIdx.x] + tid; r <= a.nreads; r += TPB) {
+    for (uint64_t r = tile_first_read + tid; r <= a.nreads; r += TPB) {
       int64_t s = (int64_t)a.offsets[r] + lo;
       if (s > last) break;
       if (s >= first) {
@@ -292,7 +297,7 @@ template <int NL, int MODE, int FMT>
 __global__ __launch_bounds__(TPB) void kc_extract_kernel(ExtractArgs a, Table t, uint64_t *ctrs) {
   __shared__ TileLDS L;
   const int64_t T0 = (int64_t)(a.tile0 + blockIdx.x) * TILE;
-  stage_tile<FMT>(L, a, T0, ctrs);
+  stage_tile<FMT>(L, a, T0, ctrs, threadIdx.x, FMT == FMT_READS ? a.tile_first[blockIdx.x] : 0, true);
   const int64_t lo = a.align, hi = (int64_t)a.align + (int64_t)a.total;
   uint32_t n_ins = 0;
 #pragma unroll 1
@@ -340,7 +345,8 @@ __global__ __launch_bounds__(TPB) void kc_extract_kernel(ExtractArgs a, Table t,
 }
 
 template <int NL>
-__global__ __launch_bounds__(TPB) void kc_insert_records_kernel(const uint64_t *recs, uint64_t n, Table t, uint64_t *ctrs) {
+__global__ __launch_bounds__(TPB) void kc_insert_records_kernel(const uint64_t *recs, uint64_t n, Table t, uint64_t *ctrs,
+                                                                 uint32_t count_inserted) {
   const uint64_t stride = (uint64_t)gridDim.x * TPB;
   uint32_t n_ins = 0;
   for (uint64_t i = (uint64_t)blockIdx.x * TPB + threadIdx.x; i < n; i += stride) {
@@ -351,7 +357,7 @@ __global__ __launch_bounds__(TPB) void kc_insert_records_kernel(const uint64_t *
     n_ins++;
   }
   for (int o = 32; o > 0; o >>= 1) n_ins += __shfl_down(n_ins, o);
-  if (lane_id() == 0 && n_ins) atomicAdd((unsigned long long *)&ctrs[CTR_INSERTED], (unsigned long long)n_ins);
+  if (count_inserted && lane_id() == 0 && n_ins) atomicAdd((unsigned long long *)&ctrs[CTR_INSERTED], (unsigned long long)n_ins);
 }
 
 // first read whose start lies at or after each tile's first position (lower bound on the offsets)

@@ -14,7 +14,7 @@ import ctypes as C
 import numpy as np
 
 from . import _lib
-from ._lib import check, kc_config, kc_kernel_time, kc_result, kc_stats, kc_synth_params, lib
+from ._lib import check, kc_config, kc_kernel_time, kc_result, kc_stats, kc_synth_params, kc_tuning, lib
 
 
 def _ptr(a):
@@ -53,10 +53,12 @@ def synth_reads_host(nreads, first_read=0, params=None):
 class KmerCounter:
     """One shard (one GPU) of the k-mer analysis stage."""
 
-    def __init__(self, kmer_len, qual_offset=33, dmin_thres=2, device=0, rank_me=0, rank_n=1, max_elems=0, time_kernels=False):
+    def __init__(self, kmer_len, qual_offset=33, dmin_thres=2, device=0, rank_me=0, rank_n=1, max_elems=0, time_kernels=False,
+                 max_kmers_buffered=0, tuning=None):
         L = lib()
         cfg = kc_config(kmer_len=kmer_len, qual_offset=qual_offset, dmin_thres=dmin_thres, device=device, rank_me=rank_me,
-                        rank_n=rank_n, max_elems=max_elems, flags=_lib.KC_FLAG_TIME_KERNELS if time_kernels else 0, reserved=0)
+                        rank_n=rank_n, max_elems=max_elems, flags=_lib.KC_FLAG_TIME_KERNELS if time_kernels else 0, reserved=0,
+                        max_kmers_buffered=max_kmers_buffered)
         st = C.c_int(0)
         self._h = L.kc_create(C.byref(cfg), C.byref(st))
         if not self._h:
@@ -64,6 +66,19 @@ class KmerCounter:
         self.k = kmer_len
         self.nl = L.kc_num_longs(kmer_len)
         self.rank_me, self.rank_n = rank_me, rank_n
+        self._tuning = tuning
+        if tuning:
+            self.set_tuning(**tuning)
+
+    def set_tuning(self, **kw):
+        """Geometry overrides of the bucketed path (tests / tuning): mode, writers, p1, p2, slots,
+        seg_capacity, reg_capacity, ovf_capacity."""
+        t = kc_tuning()
+        for k, v in kw.items():
+            if not hasattr(t, k):
+                raise TypeError("unknown tuning field %r" % k)
+            setattr(t, k, v)
+        check(lib().kc_set_tuning(self._h, C.byref(t)), "kc_set_tuning")
 
     def close(self):
         if getattr(self, "_h", None):
@@ -87,6 +102,8 @@ class KmerCounter:
 
     def reset(self, new_kmer_len=0):
         check(lib().kc_reset(self._h, new_kmer_len), "kc_reset")
+        if self._tuning:
+            self.set_tuning(**self._tuning)
         if new_kmer_len:
             self.k = new_kmer_len
             self.nl = lib().kc_num_longs(new_kmer_len)

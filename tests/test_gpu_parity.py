@@ -30,13 +30,23 @@ def arrays(reads, quals):
     return O.reads_to_arrays(reads, quals)
 
 
+# the two insert paths of the library: bucketed (LDS-counted regions, the default) and the global table;
+# "small" forces a real two-level partition with several writers on inputs the oracle finishes in seconds
+PATHS = {
+    "bucketed": None,
+    "bucketed-small": dict(writers=3, p1=4, p2=8, slots=512),
+    "table": dict(mode=1),
+}
+
+
+@pytest.mark.parametrize("path", list(PATHS))
 @pytest.mark.parametrize("k", [21, 29, 33, 51, 55, 64, 77, 99])
-def test_random_reads_match_oracle(k):
+def test_random_reads_match_oracle(k, path):
     rng = np.random.default_rng(100 + k)
     reads, quals = random_reads(rng, 1500, min_len=max(3, k - 5), max_len=k + 130, genome_len=3000)
     b, q, offs = arrays(reads, quals)
     want, wtable, wst = oracle_run(b, q, offs, k)
-    with pkg.KmerCounter(k) as kc:
+    with pkg.KmerCounter(k, tuning=PATHS[path]) as kc:
         kc.submit_reads(b, q, offs)
         kc.flush()
         gtable = kc.dump_table()
@@ -231,7 +241,7 @@ def test_table_grows_instead_of_dropping():
     reads = [genome[i:i + 150] for i in range(0, 200000 - 150, 60)] * 2
     b, q, offs = arrays(reads, None)
     want, _, wst = oracle_run(b, q, offs, k, nranks=2)
-    with pkg.KmerCounter(k, max_elems=1000) as kc:
+    with pkg.KmerCounter(k, max_elems=1000, tuning=dict(mode=1)) as kc:
         cap0 = kc.stats()["capacity"]
         kc.submit_reads(b, q, offs)
         got = kc.sorted_results()
@@ -245,14 +255,17 @@ def test_reset_reuses_the_arena_across_k():
     rng = np.random.default_rng(14)
     reads, quals = random_reads(rng, 600, min_len=40, max_len=180, genome_len=2500)
     b, q, offs = arrays(reads, quals)
-    with pkg.KmerCounter(21, max_elems=200000) as kc:
-        bytes0 = kc.stats()["table_bytes"]
-        for k in (21, 33, 55, 77, 21):
-            kc.reset(k)
-            kc.submit_reads(b, q, offs)
-            want, _, _ = oracle_run(b, q, offs, k)
-            assert_same(kc.sorted_results(), want)
-            assert kc.stats()["table_bytes"] == bytes0
+    for tuning in (None, dict(mode=1)):
+        with pkg.KmerCounter(21, max_elems=200000, max_kmers_buffered=1 << 20, tuning=tuning) as kc:
+            sizes = {}
+            for k in (21, 33, 55, 77, 21, 33):
+                kc.reset(k)
+                kc.submit_reads(b, q, offs)
+                want, _, _ = oracle_run(b, q, offs, k)
+                assert_same(kc.sorted_results(), want)
+                # coming back to a record width seen before does not allocate more than the sweep already holds
+                sizes.setdefault(kc.nl, kc.stats()["table_bytes"])
+                assert kc.stats()["table_bytes"] <= max(sizes.values())
 
 
 def test_dmin_thres_is_honoured():
@@ -279,3 +292,72 @@ def test_device_and_host_generators_agree():
         kc.synth_reads_device(db, dq, do, n, first_read=123, params=p)
     assert (db.cpu().numpy() == b).all() and (dq.cpu().numpy() == q).all()
     assert (do.cpu().numpy().astype(np.uint64) == offs).all()
+
+
+# ---- bucketed path: the branches that only unusual data reaches -------------------------------------
+def _reads_for_overflow(seed=21, n=1200):
+    rng = np.random.default_rng(seed)
+    return random_reads(rng, n, min_len=40, max_len=160, genome_len=4000)
+
+
+@pytest.mark.parametrize("k", [21, 51])
+@pytest.mark.parametrize("tuning", [
+    dict(writers=2, p1=2, p2=4, slots=4096, seg_capacity=200, ovf_capacity=1 << 20),   # level-1 segments overflow
+    dict(writers=2, p1=2, p2=4, slots=4096, reg_capacity=300, ovf_capacity=1 << 20),   # region arrays overflow
+    dict(writers=2, p1=2, p2=4, slots=64),                                             # more distinct k-mers than LDS slots
+    dict(writers=4, p1=8, p2=8, slots=128, seg_capacity=150, reg_capacity=400, ovf_capacity=1 << 20),  # all at once
+], ids=["seg-overflow", "region-overflow", "lds-full", "everything"])
+def test_overflow_paths_are_exact(k, tuning):
+    reads, quals = _reads_for_overflow(21 + k)
+    b, q, offs = arrays(reads, quals)
+    want, wtable, wst = oracle_run(b, q, offs, k)
+    with pkg.KmerCounter(k, tuning=tuning) as kc:
+        kc.submit_reads(b, q, offs)
+        gtable = kc.dump_table()
+        got = kc.sorted_results()
+        st = kc.stats()
+    assert_same(got, want)
+    assert (gtable[0] == wtable[0]).all() and (gtable[1] == wtable[1]).all() and (gtable[2] == wtable[2]).all()
+    assert st["num_unique"] == wst["unique"] and st["num_purged"] == wst["purged"] and st["sum_counts"] == wst["sum_counts"]
+
+
+def test_exhausted_overflow_list_is_an_error_not_a_loss():
+    reads, quals = _reads_for_overflow()
+    b, q, offs = arrays(reads, quals)
+    with pkg.KmerCounter(21, tuning=dict(writers=2, p1=2, p2=4, seg_capacity=100, ovf_capacity=50)) as kc:
+        with pytest.raises(pkg.KcError) as e:
+            kc.submit_reads(b, q, offs)
+            kc.results()
+        assert e.value.status == -6
+
+
+def test_full_buffer_falls_back_to_the_table_path():
+    k = 21
+    reads, quals = _reads_for_overflow(5, n=2000)
+    b, q, offs = arrays(reads, quals)
+    want, _, wst = oracle_run(b, q, offs, k)
+    with pkg.KmerCounter(k, max_kmers_buffered=50000) as kc:  # far fewer than the ~170k occurrences
+        for r0 in range(0, 2000, 250):
+            bb, qq, oo = arrays(reads[r0:r0 + 250], quals[r0:r0 + 250])
+            kc.submit_reads(bb, qq, oo)
+        got = kc.sorted_results()
+        st = kc.stats()
+    assert_same(got, want)
+    assert st["num_unique"] == wst["unique"] and st["kmers_inserted"] == wst["kmers_inserted"]
+
+
+def test_heavy_hitter_kmers():
+    # one k-mer in almost every read: a region far above its mean size, counters far above the rest
+    k = 21
+    rng = np.random.default_rng(33)
+    rep = "ACGTTGCATGCATGCCGATTACGG"
+    reads = []
+    for _ in range(3000):
+        tail = "".join(rng.choice(list("ACGT"), size=40))
+        reads.append(tail[:20] + rep + tail[20:])
+    b, q, offs = arrays(reads, None)
+    want, _, _ = oracle_run(b, q, offs, k)
+    for tuning in (None, dict(writers=4, p1=4, p2=4, slots=2048)):
+        with pkg.KmerCounter(k, tuning=tuning) as kc:
+            kc.submit_reads(b, q, offs)
+            assert_same(kc.sorted_results(), want)

@@ -34,6 +34,7 @@ def parse_args():
     ap.add_argument("--block-reads", type=int, default=4_000_000, help="N>1: reads per exchange block")
     ap.add_argument("--cpu-sample-reads", type=int, default=1_000_000, help="reads timed through the CPU oracle (0 = skip)")
     ap.add_argument("--check", action="store_true", help="size-independent result checks after the timed region")
+    ap.add_argument("--table-path", action="store_true", help="A/B: force the global-table insert path instead of the bucketed one")
     return ap.parse_args()
 
 
@@ -105,7 +106,9 @@ def main():
     # distinct k-mers: genomes (shared by all ranks) + ~k per substitution error
     genome_kmers = 64 * 4_000_000
     est_unique = int((genome_kmers + world * nreads * L * params.sub_error_rate * k * 1.05) / world) + (1 << 20)
-    kc = pkg.KmerCounter(k, device=local_rank, rank_me=rank, rank_n=world, max_elems=est_unique, time_kernels=True)
+    ap_tuning = dict(mode=1) if a.table_path else None
+    kc = pkg.KmerCounter(k, device=local_rank, rank_me=rank, rank_n=world, max_elems=est_unique, time_kernels=True,
+                         max_kmers_buffered=int(nreads * (L - k - 1) * 1.02) + (1 << 20), tuning=ap_tuning)
     kc.set_stream(torch.cuda.current_stream().cuda_stream)
     kc.synth_reads_device(d_bases, d_quals, d_offs, nreads, first_read=rank * nreads, params=params)
     torch.cuda.synchronize()

@@ -39,8 +39,8 @@ class kc_result(C.Structure):
 
 class kc_tuning(C.Structure):
     _fields_ = [("mode", C.c_uint32), ("writers", C.c_uint32), ("p1", C.c_uint32), ("p2", C.c_uint32), ("slots", C.c_uint32),
-                ("reserved", C.c_uint32), ("seg_capacity", C.c_uint64), ("reg_capacity", C.c_uint64),
-                ("ovf_capacity", C.c_uint64)]
+                ("chunk1", C.c_uint32), ("chunk2", C.c_uint32), ("chain1_max", C.c_uint32), ("chain2_max", C.c_uint32),
+                ("arena1", C.c_uint32), ("ovf_capacity", C.c_uint64)]
 
 
 class kc_kernel_time(C.Structure):

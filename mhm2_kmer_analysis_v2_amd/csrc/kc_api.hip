@@ -366,8 +366,9 @@ extern "C" int kc_reset(kc_ctx *c, int new_k) {
   if (st) return st;
   HIPCHK(hipSetDevice(c->cfg.device));
   HIPCHK(hipStreamSynchronize(c->stream));
-  free_results(c);
   const int old_nl = c->nl;
+  if (kc_num_longs(new_k) != old_nl) free_results(c);  // else the result arrays are reused by the next finalize
+  c->out_n = 0;
   c->k = new_k;
   c->cfg.kmer_len = new_k;
   c->nl = kc_num_longs(new_k);
@@ -389,6 +390,7 @@ extern "C" int kc_reset(kc_ctx *c, int new_k) {
     } else {
       const size_t R = (size_t)c->gm.P1 * c->gm.P2;
       HIPCHK(hipMemsetAsync(c->bb.cnt1, 0, (size_t)c->gm.G * c->gm.P1 * 4, c->stream));
+      HIPCHK(hipMemsetAsync(c->bb.used1, 0, (size_t)c->gm.G * 4, c->stream));
       HIPCHK(hipMemsetAsync(c->bb.cnt2, 0, R * 4, c->stream));
       HIPCHK(hipMemsetAsync(c->bb.flag, 0, R * 4, c->stream));
     }
@@ -411,13 +413,9 @@ static uint32_t count_smax(int nl) {
 
 static void bk_free(kc_ctx *c) {
   BucketBufs &b = c->bb;
-  if (b.rec1) (void)hipFree(b.rec1);
-  if (b.cnt1) (void)hipFree(b.cnt1);
-  if (b.rec2) (void)hipFree(b.rec2);
-  if (b.cnt2) (void)hipFree(b.cnt2);
-  if (b.flag) (void)hipFree(b.flag);
-  if (b.ovf1) (void)hipFree(b.ovf1);
-  if (b.ovf2) (void)hipFree(b.ovf2);
+  void *ptrs[] = {b.rec1, b.chain1, b.cnt1, b.used1, b.rec2, b.chain2, b.cnt2, b.base2, b.flag, b.ovf1, b.ovf2};
+  for (void *p : ptrs)
+    if (p) (void)hipFree(p);
   memset(&b, 0, sizeof(b));
   c->bk_ready = false;
   c->bk_bytes = 0;
@@ -429,22 +427,18 @@ static uint32_t ilog2(uint64_t v) {
   return l;
 }
 
-static uint64_t padded_capacity(double mean, double heavy) {
-  // Poisson slack (6 sigma) + room for heavy-hitter k-mers + a floor for tiny inputs
-  return (uint64_t)(mean + 6.0 * sqrt(mean) + heavy * mean) + 64;
-}
-
-// Choose the geometry from the configured sizes and allocate the level-1 / level-2 arrays.
+// Choose the geometry from the configured sizes and allocate the level-1 / level-2 arenas.
 static int bk_init(kc_ctx *c) {
   if (c->bk_ready) return KC_OK;
   const kc_tuning &t = c->tuning;
   Geom &g = c->gm;
+  memset(&g, 0, sizeof(g));
   const uint64_t bcap = c->cfg.max_kmers_buffered ? c->cfg.max_kmers_buffered : (1ULL << 26);
   const double est = c->cfg.max_elems ? (double)c->cfg.max_elems : 0.35 * (double)bcap;  // 1/depth(4) + error share, kmer_dht.cpp:126-131
   const uint32_t smax = count_smax(c->nl);
   g.S = t.slots ? std::min(std::max(t.slots, 16u), smax) : smax;
   const uint64_t regions_needed = (uint64_t)(est / (0.7 * g.S)) + 1;  // LDS tables run at ~0.7 load
-  uint32_t bits = std::min<uint32_t>(ilog2(regions_needed), 20);
+  const uint32_t bits = std::min<uint32_t>(ilog2(regions_needed), 20);
   g.log2P1 = t.p1 ? ilog2(t.p1) : bits / 2;  // level 1 holds fewer records per round than level 2: give it the smaller fan-out
   g.log2P2 = t.p2 ? ilog2(t.p2) : (bits + 1) / 2;
   if (g.log2P1 > 10 || g.log2P2 > 10) return KC_ERR_INVALID_ARG;
@@ -455,29 +449,45 @@ static int bk_init(kc_ctx *c) {
                   : (uint32_t)std::max<uint64_t>(1, std::min<uint64_t>((uint64_t)std::min<int>(c->num_cus, GMAX), bcap / (4 * 16384)));
   if (g.G < 1) g.G = 1;
   const uint64_t R = (uint64_t)g.P1 * g.P2;
-  g.C1 = t.seg_capacity ? t.seg_capacity : padded_capacity((double)bcap / ((double)g.G * g.P1), 0.08);
-  g.C2 = t.reg_capacity ? t.reg_capacity : padded_capacity((double)bcap / (double)R, 0.15);
-  if (g.C1 >= (1ULL << 31) || g.C2 >= (1ULL << 31) || bcap / g.P1 >= (1ULL << 31)) return KC_ERR_INVALID_ARG;
+  // chunk sizes: at most ~1/8 of a destination's mean share, within [16, 512] / [16, 1024] records
+  const double mean1 = (double)bcap / ((double)g.G * g.P1), mean2 = (double)bcap / (double)R;
+  g.log2CH1 = t.chunk1 ? ilog2(t.chunk1) : std::min<uint32_t>(9, std::max<uint32_t>(4, ilog2((uint64_t)(mean1 / 8) + 1)));
+  g.log2CH2 = t.chunk2 ? ilog2(t.chunk2) : std::min<uint32_t>(10, std::max<uint32_t>(4, ilog2((uint64_t)(mean2 / 8) + 1)));
+  const uint64_t CH1 = 1ULL << g.log2CH1, CH2 = 1ULL << g.log2CH2;
+  // chains may grow to several times the mean: k-mer multiplicities are heavy-tailed
+  g.L1MAX = t.chain1_max ? t.chain1_max : (uint32_t)(4.0 * mean1 / (double)CH1) + 8;
+  g.L2MAX = t.chain2_max ? t.chain2_max : (uint32_t)(4.0 * mean2 / (double)CH2) + 8;
+  g.A1 = t.arena1 ? t.arena1 : (uint32_t)(1.03 * (double)bcap / ((double)g.G * (double)CH1)) + g.P1 + 16;
+  const uint64_t a2 = bcap / CH2 + R + g.P1 + 16;
+  if (a2 >= (1ULL << 32) || (uint64_t)g.A1 * g.G >= (1ULL << 32) || bcap / g.P1 >= (1ULL << 31)) return KC_ERR_INVALID_ARG;
+  g.A2 = (uint32_t)a2;
   BucketBufs &b = c->bb;
   memset(&b, 0, sizeof(b));
   b.ovf1_cap = b.ovf2_cap = t.ovf_capacity ? t.ovf_capacity : bcap / 16 + 4096;
   const size_t w = (size_t)c->nl * 8;
   const size_t nseg = (size_t)g.G * g.P1;
-  HIPCHK(hipMalloc((void **)&b.rec1, nseg * g.C1 * w));
+  const size_t rec1_bytes = (size_t)g.G * g.A1 * CH1 * w, rec2_bytes = (size_t)g.A2 * CH2 * w;
+  HIPCHK(hipMalloc((void **)&b.rec1, rec1_bytes));
+  HIPCHK(hipMalloc((void **)&b.chain1, nseg * g.L1MAX * 4));
   HIPCHK(hipMalloc((void **)&b.cnt1, nseg * 4));
-  HIPCHK(hipMalloc((void **)&b.rec2, (size_t)R * g.C2 * w));
+  HIPCHK(hipMalloc((void **)&b.used1, (size_t)g.G * 4));
+  HIPCHK(hipMalloc((void **)&b.rec2, rec2_bytes));
+  HIPCHK(hipMalloc((void **)&b.chain2, (size_t)R * g.L2MAX * 4));
   HIPCHK(hipMalloc((void **)&b.cnt2, (size_t)R * 4));
+  HIPCHK(hipMalloc((void **)&b.base2, ((size_t)g.P1 + 1) * 4));
   HIPCHK(hipMalloc((void **)&b.flag, (size_t)R * 4));
   HIPCHK(hipMalloc((void **)&b.ovf1, b.ovf1_cap * w));
   HIPCHK(hipMalloc((void **)&b.ovf2, b.ovf2_cap * w));
   HIPCHK(hipMemsetAsync(b.cnt1, 0, nseg * 4, c->stream));
+  HIPCHK(hipMemsetAsync(b.used1, 0, (size_t)g.G * 4, c->stream));
   HIPCHK(hipMemsetAsync(b.cnt2, 0, (size_t)R * 4, c->stream));
   HIPCHK(hipMemsetAsync(b.flag, 0, (size_t)R * 4, c->stream));
   HIPCHK(hipMemsetAsync(c->d_cb, 0, CB_COUNT * 8, c->stream));
-  c->bk_bytes = nseg * g.C1 * w + (size_t)R * g.C2 * w + (b.ovf1_cap + b.ovf2_cap) * w + nseg * 4 + (size_t)R * 8;
+  c->bk_bytes = rec1_bytes + rec2_bytes + (b.ovf1_cap + b.ovf2_cap) * w + nseg * (g.L1MAX + 1) * 4 + (size_t)R * (g.L2MAX + 2) * 4;
   c->bk_capacity = bcap;
   c->bk_ready = true;
   c->bk_level2 = c->bk_flagged = false;
+  c->bk_rot = 0;
   return KC_OK;
 }
 
@@ -493,19 +503,19 @@ static int set_dyn_lds(K kernel, size_t bytes) {
   return KC_OK;
 }
 
-static size_t lds_l1_reads() { return ((sizeof(L1LDS) + 15) & ~size_t(15)) + STAGE_BYTES; }
-static size_t lds_l1_records() { return ((sizeof(L1RLDS) + 15) & ~size_t(15)) + STAGE_BYTES; }
-static size_t lds_l2() { return ((sizeof(L2LDS) + 15) & ~size_t(15)) + STAGE_BYTES; }
+template <int NL> static size_t lds_l1_reads() { return ((sizeof(L1LDS) + 15) & ~size_t(15)) + Rnd<NL>::STAGE_READS; }
+template <int NL> static size_t lds_l1_records() { return ((sizeof(L1RLDS) + 15) & ~size_t(15)) + Rnd<NL>::STAGE; }
+template <int NL> static size_t lds_l2() { return ((sizeof(L2LDS) + 15) & ~size_t(15)) + Rnd<NL>::STAGE; }
 
 template <int NL, int FMT>
 static int launch_l1_reads_t(kc_ctx *c, const ExtractArgs &a, uint64_t ntiles) {
   auto kern = kc_l1_reads_kernel<NL, FMT>;
-  int rc = set_dyn_lds(kern, lds_l1_reads());
+  int rc = set_dyn_lds(kern, lds_l1_reads<NL>());
   if (rc) return rc;
   const uint64_t nsuper = (ntiles + QUARTERS - 1) / QUARTERS;
   const unsigned grid = (unsigned)std::min<uint64_t>(c->gm.G, nsuper);
   KernelTimer kt(c, KT_L1_READS);
-  hipLaunchKernelGGL(kern, dim3(grid), dim3(WGB), lds_l1_reads(), c->stream, a, c->gm, c->bb, ntiles, c->bk_rot, c->d_ctrs, c->d_cb);
+  hipLaunchKernelGGL(kern, dim3(grid), dim3(WGB), lds_l1_reads<NL>(), c->stream, a, c->gm, c->bb, ntiles, c->bk_rot, c->d_ctrs, c->d_cb);
   c->bk_rot = (uint32_t)((c->bk_rot + nsuper) % c->gm.G);
   return KC_OK;
 }
@@ -530,12 +540,12 @@ static int launch_l1_reads(kc_ctx *c, const ExtractArgs &a, uint64_t ntiles, int
 template <int NL>
 static int launch_l1_records_t(kc_ctx *c, const uint64_t *recs, uint64_t n) {
   auto kern = kc_l1_records_kernel<NL>;
-  int rc = set_dyn_lds(kern, lds_l1_records());
+  int rc = set_dyn_lds(kern, lds_l1_records<NL>());
   if (rc) return rc;
   const uint64_t per_round = (uint64_t)WGB * Rnd<NL>::RPOS;
   const unsigned grid = (unsigned)std::min<uint64_t>(c->gm.G, (n + per_round - 1) / per_round);
   KernelTimer kt(c, KT_L1_RECORDS);
-  hipLaunchKernelGGL(kern, dim3(grid), dim3(WGB), lds_l1_records(), c->stream, recs, n, c->gm, c->bb, c->bk_rot, c->d_ctrs, c->d_cb);
+  hipLaunchKernelGGL(kern, dim3(grid), dim3(WGB), lds_l1_records<NL>(), c->stream, recs, n, c->gm, c->bb, c->bk_rot, c->d_ctrs, c->d_cb);
   c->bk_rot = (uint32_t)((c->bk_rot + (n + per_round - 1) / per_round) % c->gm.G);
   return KC_OK;
 }
@@ -577,6 +587,7 @@ static int bk_drain_to_table(kc_ctx *c) {
   if (rc) return rc;
   HIPCHK(hipGetLastError());
   HIPCHK(hipMemsetAsync(c->bb.cnt1, 0, (size_t)c->gm.G * c->gm.P1 * 4, c->stream));
+  HIPCHK(hipMemsetAsync(c->bb.used1, 0, (size_t)c->gm.G * 4, c->stream));
   HIPCHK(hipMemsetAsync(c->d_cb, 0, CB_COUNT * 8, c->stream));
   c->table_mode = true;
   return KC_OK;
@@ -635,7 +646,7 @@ static int run_extract_device(kc_ctx *c, const uint8_t *bases, const uint8_t *qu
   a.records = d_records;
   a.seg_capacity = seg_capacity;
   const uint64_t ntiles_total = (a.align + total + TILE - 1) / TILE;
-  uint64_t buffered = 0;
+  bool over_capacity = false;
   if (mode == MODE_INSERT) {
     c->started = true;
     if (bk_active(c)) {
@@ -644,7 +655,8 @@ static int run_extract_device(kc_ctx *c, const uint8_t *bases, const uint8_t *qu
       rc = sync_ctrs(c);
       if (rc) return rc;
       if (c->h_ctrs[CTR_BAD_BASE]) return KC_ERR_BAD_BASE;
-      buffered = c->h_ctrs[CTR_INSERTED];
+      // the stats kernel of this block has run: CTR_EXPECT counts every occurrence submitted so far, this block included
+      over_capacity = c->h_ctrs[CTR_EXPECT] > c->bk_capacity;
     }
   }
   uint64_t t0 = 0;
@@ -659,7 +671,7 @@ static int run_extract_device(kc_ctx *c, const uint8_t *bases, const uint8_t *qu
       chunk_tiles = std::min<uint64_t>(chunk_tiles, (1ULL << 28) / TILE);
     }
     const uint64_t nt = std::min(chunk_tiles, ntiles_total - t0);
-    if (bk && buffered + nt * TILE > c->bk_capacity) {
+    if (bk && over_capacity) {
       int rc = bk_drain_to_table(c);  // out of buffer room: this and every later chunk take the table path
       if (rc) return rc;
       continue;
@@ -682,7 +694,6 @@ static int run_extract_device(kc_ctx *c, const uint8_t *bases, const uint8_t *qu
     if (bk) {
       int rc = launch_l1_reads(c, a, nt, fmt);
       if (rc) return rc;
-      buffered += nt * TILE;
     } else {
       launch_extract(c, a, (unsigned)nt, mode, fmt);
     }
@@ -857,7 +868,7 @@ extern "C" int kc_insert_records(kc_ctx *c, const uint64_t *d_records, uint64_t 
     if (rc) return rc;
     rc = sync_ctrs(c);
     if (rc) return rc;
-    if (c->h_ctrs[CTR_INSERTED] + n > c->bk_capacity) {
+    if (c->h_ctrs[CTR_EXPECT] + n > c->bk_capacity) {
       rc = bk_drain_to_table(c);
       if (rc) return rc;
     } else {
@@ -893,8 +904,12 @@ static void launch_finalize(kc_ctx *c) {
 }
 
 static int alloc_results(kc_ctx *c, uint64_t cap) {
-  free_results(c);
   if (!cap) cap = 1;
+  if (c->d_out_keys && c->out_cap >= cap) {  // the arrays of an earlier run are big enough: keep them
+    c->out_n = 0;
+    return KC_OK;
+  }
+  free_results(c);
   HIPCHK(hipMalloc((void **)&c->d_out_keys, cap * c->nl * 8));
   HIPCHK(hipMalloc((void **)&c->d_out_counts, cap * 2));
   HIPCHK(hipMalloc((void **)&c->d_out_left, cap));
@@ -952,11 +967,13 @@ static int table_finalize_append(kc_ctx *c) {
 template <int NL>
 static int bk_level2_t(kc_ctx *c) {
   auto kern = kc_l2_split_kernel<NL>;
-  int rc = set_dyn_lds(kern, lds_l2());
+  int rc = set_dyn_lds(kern, lds_l2<NL>());
   if (rc) return rc;
+  hipLaunchKernelGGL(kc_bucket_prefix_kernel, dim3(1), dim3(WGB), 0, c->stream, c->gm, c->bb, c->d_cb);
+  c->num_gpu_calls++;
   {
     KernelTimer kt(c, KT_L2_SPLIT);
-    hipLaunchKernelGGL(kern, dim3(std::min<unsigned>(c->gm.P1, (unsigned)c->num_cus)), dim3(WGB), lds_l2(), c->stream, c->gm, c->bb, c->d_cb);
+    hipLaunchKernelGGL(kern, dim3(std::min<unsigned>(c->gm.P1, (unsigned)c->num_cus)), dim3(WGB), lds_l2<NL>(), c->stream, c->gm, c->bb, c->d_cb);
   }
   HIPCHK(hipGetLastError());
   rc = sync_cb(c);
@@ -1270,7 +1287,9 @@ extern "C" int kc_set_tuning(kc_ctx *c, const kc_tuning *t) {
   if (!c || !t) return KC_ERR_INVALID_ARG;
   if (c->started) return KC_ERR_STATE;
   if (t->mode > 1) return KC_ERR_INVALID_ARG;
-  if ((t->p1 && (t->p1 & (t->p1 - 1))) || (t->p2 && (t->p2 & (t->p2 - 1))) || t->p1 > PMAX || t->p2 > PMAX || t->writers > GMAX)
+  auto pow2_or_zero = [](uint32_t v) { return (v & (v - 1)) == 0; };
+  if (!pow2_or_zero(t->p1) || !pow2_or_zero(t->p2) || !pow2_or_zero(t->chunk1) || !pow2_or_zero(t->chunk2) || t->p1 > PMAX ||
+      t->p2 > PMAX || t->writers > GMAX)
     return KC_ERR_INVALID_ARG;
   HIPCHK(hipSetDevice(c->cfg.device));
   HIPCHK(hipStreamSynchronize(c->stream));

@@ -31,34 +31,45 @@ namespace kc {
 constexpr int WGB = 1024;        // threads per workgroup in this file (16 waves: one workgroup per CU)
 constexpr int QUARTERS = WGB / TPB;
 constexpr int PMAX = 1024;       // max fan-out of either level
-constexpr int GMAX = 1024;       // max level-1 writers
+constexpr int GMAX = 512;        // max level-1 writers
 
-// records held per thread and round, by key width (bounds registers and the LDS staging area)
 // RPOS: when the records come from memory; RPOS_READS: when each is cut out of a staged tile (more live registers)
 template <int NL> struct Rnd {
   static constexpr int RPOS = NL == 1 ? 16 : NL == 2 ? 8 : 4;
-  static constexpr int RPOS_READS = NL <= 2 ? 8 : 4;
+  static constexpr int RPOS_READS = NL == 1 ? 8 : NL <= 3 ? 4 : 2;
+  // sorted staging of one round: <= 128 KiB from memory, <= 96 KiB from tiles (the tiles need LDS too)
+  static constexpr size_t STAGE = (size_t)WGB * RPOS * NL * 8;
+  static constexpr size_t STAGE_READS = (size_t)WGB * RPOS_READS * NL * 8;
 };
-constexpr int STAGE_BYTES = 131072;  // sorted staging: WGB * RPOS * NL * 8 <= 128 KiB for every NL
 
+// Destination arrays are chains of fixed-size chunks taken from an arena that only its owner allocates
+// from (a level-1 writer; a level-2 bucket), so appends need no global atomics and a destination that
+// grows far beyond the mean (k-mer counts are heavy-tailed) costs no memory up front.
 struct Geom {
-  uint32_t G, P1, P2, S;     // writers, fan-outs (powers of two), LDS slots per region
+  uint32_t G, P1, P2, S;       // writers, fan-outs (powers of two), LDS slots per region
   uint32_t log2P1, log2P2;
-  uint64_t C1, C2;           // capacity in records of one (writer,bucket) segment / one region array
+  uint32_t log2CH1, log2CH2;   // records per chunk (powers of two)
+  uint32_t L1MAX, L2MAX;       // longest chain of a (writer,bucket) segment / of a region, in chunks
+  uint32_t A1;                 // chunks in each writer's arena
+  uint32_t A2;                 // chunks in the level-2 arena (all buckets)
 };
 
 struct BucketBufs {
-  uint64_t *rec1;    // [G][P1][C1] records
-  uint32_t *cnt1;    // [G][P1]
-  uint64_t *rec2;    // [P1*P2][C2]
-  uint32_t *cnt2;    // [P1*P2]
-  uint32_t *flag;    // [P1*P2]: 0 fine, 1 array overflowed (level 2), 2 more distinct k-mers than slots (count)
-  uint64_t *ovf1;    // level-1 overflow: records without a home segment
-  uint64_t *ovf2;    // level-2 overflow: records of flagged regions
+  uint64_t *rec1;      // [G][A1] chunks of CH1 records
+  uint32_t *chain1;    // [G*P1][L1MAX] chunk index within the writer's arena
+  uint32_t *cnt1;      // [G*P1] records in the chain
+  uint32_t *used1;     // [G] chunks taken from each writer's arena
+  uint64_t *rec2;      // [A2] chunks of CH2 records
+  uint32_t *chain2;    // [P1*P2][L2MAX] chunk index in rec2
+  uint32_t *cnt2;      // [P1*P2] records in the chain
+  uint32_t *base2;     // [P1+1] first chunk of each bucket's private part of the level-2 arena
+  uint32_t *flag;      // [P1*P2]: 0 fine, 1 chain overflowed (level 2), 2 more distinct k-mers than slots (count)
+  uint64_t *ovf1;      // level-1 overflow: records without a home segment
+  uint64_t *ovf2;      // level-2 overflow: records of flagged regions
   uint64_t ovf1_cap, ovf2_cap;
 };
 
-enum {  // more counters (continue kc_kernels.hpp's list inside the CTR_BIN0.. block is not possible: own block)
+enum {  // counters of this path, one u64 each
   CB_OVF1 = 0, CB_OVF2, CB_FATAL, CB_FLAGGED_RECS, CB_DUMP, CB_ENTRIES, CB_COUNT = 16
 };
 
@@ -114,27 +125,54 @@ __device__ __forceinline__ uint32_t block_excl_scan(uint32_t v, ScanLDS &S) {
 struct SplitLDS {
   uint32_t hist[2][PMAX];  // per-bucket counts of this round (double-buffered); becomes "fit" after the scan
   uint32_t offs[PMAX];     // exclusive prefix: where the bucket's run starts in the sorted staging
-  uint32_t dbase[PMAX];    // where the run goes in the bucket's destination array
-  uint32_t cur[PMAX];      // fill of each destination array owned by this workgroup
+  uint32_t dbase[PMAX];    // position in the destination chain where the run starts
+  uint32_t cur[PMAX];      // records in each destination chain owned by this workgroup
+  uint32_t c0[PMAX];       // chunk that holds position dbase
+  uint32_t last[PMAX];     // last chunk of the chain
+  uint32_t arena_used;     // chunks taken from the owner's arena
   ScanLDS scan;
+};
+
+// where the destinations of the current owner live
+struct ChainDest {
+  uint64_t *arena;      // chunk id c starts at arena + (c << log2CH) * NL
+  uint32_t *chain;      // destination b's chain: chain[b*LMAX + i]
+  uint32_t log2CH, LMAX;
+  uint32_t arena_cap;   // chunks this owner may take
+  uint32_t arena_base;  // id of the owner's first chunk
 };
 
 // Phase 2-4 of a round: scan, reserve, scatter to LDS, copy out.  The caller has already bumped
 // hist[buf] with LDS atomics (bucket | rank<<10 in br[], ~0 for "no record") and hit a barrier.
-//   dest(b)  -> pointer to the destination array of bucket b (records), capacity cap
-//   bucket_of(hash) recomputes a record's bucket during copy-out
-template <int NL, int R, class DestFn, class BucketFn, class OvfFn>
+//   bucket_of(hash) recomputes a record's bucket during copy-out; overflow(b, rec) takes what found no room
+template <int NL, int R, class BucketFn, class OvfFn>
 __device__ __forceinline__ void split_round(SplitLDS &L, uint64_t *sorted, int buf, uint32_t P, const uint64_t (&rec)[R][NL],
-                                            const uint32_t (&br)[R], uint64_t cap, DestFn dest, BucketFn bucket_of, OvfFn overflow) {
+                                            const uint32_t (&br)[R], const ChainDest &D, BucketFn bucket_of, OvfFn overflow) {
   const int tid = threadIdx.x;
   uint32_t *H = L.hist[buf];
   const uint32_t v = ((uint32_t)tid < P) ? H[tid] : 0u;
   const uint32_t excl = block_excl_scan(v, L.scan);
+  const uint32_t CHm = (1u << D.log2CH) - 1u;
   if ((uint32_t)tid < P) {
     L.offs[tid] = excl;
     const uint32_t base = L.cur[tid];
-    const uint64_t room = cap - (uint64_t)base;
-    const uint32_t fit = (uint64_t)v <= room ? v : (uint32_t)room;
+    uint32_t fit = v;
+    const uint64_t room = ((uint64_t)D.LMAX << D.log2CH) - base;  // the chain holds at most LMAX chunks
+    if ((uint64_t)fit > room) fit = (uint32_t)room;
+    const uint32_t have = (base + CHm) >> D.log2CH;
+    uint32_t k = ((base + fit + CHm) >> D.log2CH) - have, a = 0;
+    if (k) {
+      a = atomicAdd(&L.arena_used, k);
+      if (a + k > D.arena_cap) {  // arena exhausted: use what is left of it, the rest overflows
+        k = a < D.arena_cap ? D.arena_cap - a : 0;
+        const uint64_t cap = ((uint64_t)(have + k) << D.log2CH) - base;
+        if ((uint64_t)fit > cap) fit = (uint32_t)cap;
+      }
+      uint32_t *ch = D.chain + (size_t)tid * D.LMAX + have;
+      for (uint32_t i = 0; i < k; i++) ch[i] = D.arena_base + a + i;
+    }
+    L.c0[tid] = (base & CHm) ? L.last[tid] : D.arena_base + a;  // only read when fit > 0, and then k > 0 if base is chunk-aligned
+    if (k) L.last[tid] = D.arena_base + a + k - 1;
     L.dbase[tid] = base;
     H[tid] = fit;
     L.cur[tid] = base + fit;
@@ -159,7 +197,12 @@ __device__ __forceinline__ void split_round(SplitLDS &L, uint64_t *sorted, int b
     const uint32_t b = bucket_of(rec_hash<NL>(r));
     const uint32_t j = i - L.offs[b];
     if (j < H[b]) {
-      uint64_t *d = dest(b) + ((size_t)L.dbase[b] + j) * NL;
+      const uint32_t p = L.dbase[b] + j, ci = p >> D.log2CH;
+      // runs are short against a chunk: nearly always the chunk the run starts in
+      const uint32_t cid = (ci == (L.dbase[b] >> D.log2CH))
+                               ? L.c0[b]
+                               : __hip_atomic_load(&D.chain[(size_t)b * D.LMAX + ci], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      uint64_t *d = D.arena + (((size_t)cid << D.log2CH) + (p & CHm)) * NL;
 #pragma unroll
       for (int w = 0; w < NL; w++) d[w] = r[w];
     } else {
@@ -169,11 +212,49 @@ __device__ __forceinline__ void split_round(SplitLDS &L, uint64_t *sorted, int b
   __syncthreads();
 }
 
+// load the persistent state of this owner's P chains (before its first round)
+__device__ __forceinline__ void split_load_state(SplitLDS &L, uint32_t P, const uint32_t *cnt, const uint32_t *chain, uint32_t LMAX,
+                                                 uint32_t log2CH, uint32_t arena_base, uint32_t used) {
+  const int tid = threadIdx.x;
+  if ((uint32_t)tid < P) {
+    const uint32_t c = cnt ? cnt[tid] : 0u;
+    L.cur[tid] = c;
+    L.last[tid] = (c & ((1u << log2CH) - 1u)) ? chain[(size_t)tid * LMAX + (c >> log2CH)] : 0u;
+    L.hist[0][tid] = 0;
+    L.hist[1][tid] = 0;
+  }
+  if (tid == 0) L.arena_used = used;
+  (void)arena_base;
+}
+
 // ---- level 1 from reads ---------------------------------------------------------------------------
 struct L1LDS {
   TileLDS tile[QUARTERS];
   SplitLDS sp;
 };
+
+template <int NL>
+__device__ __forceinline__ ChainDest l1_dest(const Geom &gm, const BucketBufs &bb, uint32_t g) {
+  ChainDest D;
+  D.arena = bb.rec1 + (((size_t)g * gm.A1) << gm.log2CH1) * NL;
+  D.chain = bb.chain1 + (size_t)g * gm.P1 * gm.L1MAX;
+  D.log2CH = gm.log2CH1;
+  D.LMAX = gm.L1MAX;
+  D.arena_cap = gm.A1;
+  D.arena_base = 0;
+  return D;
+}
+
+template <int NL>
+__device__ __forceinline__ void l1_overflow(const BucketBufs &bb, uint64_t *cb, const uint64_t (&r)[NL]) {
+  const uint64_t o = atomicAdd((unsigned long long *)&cb[CB_OVF1], 1ULL);
+  if (o < bb.ovf1_cap) {
+#pragma unroll
+    for (int w = 0; w < NL; w++) bb.ovf1[o * NL + w] = r[w];
+  } else {
+    cb[CB_FATAL] = 1;
+  }
+}
 
 template <int NL, int FMT>
 __global__ __launch_bounds__(WGB) void kc_l1_reads_kernel(ExtractArgs a, Geom gm, BucketBufs bb, uint64_t ntiles, uint32_t rot,
@@ -185,17 +266,13 @@ __global__ __launch_bounds__(WGB) void kc_l1_reads_kernel(ExtractArgs a, Geom gm
   const int tid = threadIdx.x, q = tid >> 8, qt = tid & (TPB - 1);
   // writer id: launches rotate their first writer (rot) so that many small submits still spread evenly
   const uint32_t g = (blockIdx.x + rot) % gm.G, P1 = gm.P1;
-  if ((uint32_t)tid < P1) {
-    L.sp.cur[tid] = bb.cnt1[(size_t)g * P1 + tid];
-    L.sp.hist[0][tid] = 0;
-    L.sp.hist[1][tid] = 0;
-  }
+  const ChainDest D = l1_dest<NL>(gm, bb, g);
+  split_load_state(L.sp, P1, bb.cnt1 + (size_t)g * P1, D.chain, D.LMAX, D.log2CH, 0, bb.used1[g]);
   __syncthreads();
   const int64_t lo = a.align, hi = (int64_t)a.align + (int64_t)a.total;
   const uint64_t nsuper = (ntiles + QUARTERS - 1) / QUARTERS;
   uint32_t n_ins = 0;
   int buf = 0;
-  uint64_t *seg0 = bb.rec1 + (size_t)g * P1 * gm.C1 * NL;
   for (uint64_t st = blockIdx.x; st < nsuper; st += gridDim.x) {
     const uint64_t tile = st * QUARTERS + q;
     const bool active = tile < ntiles;
@@ -222,21 +299,13 @@ __global__ __launch_bounds__(WGB) void kc_l1_reads_kernel(ExtractArgs a, Geom gm
       }
       __syncthreads();
       split_round<NL, RPOS>(
-          L.sp, sorted, buf, P1, rec, br, gm.C1, [&](uint32_t b) { return seg0 + (size_t)b * gm.C1 * NL; },
-          [&](uint64_t h) { return hash_b1(h, gm); },
-          [&](uint32_t, const uint64_t (&r)[NL]) {
-            const uint64_t o = atomicAdd((unsigned long long *)&cb[CB_OVF1], 1ULL);
-            if (o < bb.ovf1_cap) {
-#pragma unroll
-              for (int w = 0; w < NL; w++) bb.ovf1[o * NL + w] = r[w];
-            } else {
-              cb[CB_FATAL] = 1;
-            }
-          });
+          L.sp, sorted, buf, P1, rec, br, D, [&](uint64_t h) { return hash_b1(h, gm); },
+          [&](uint32_t, const uint64_t (&r)[NL]) { l1_overflow<NL>(bb, cb, r); });
       buf ^= 1;
     }
   }
   if ((uint32_t)tid < P1) bb.cnt1[(size_t)g * P1 + tid] = L.sp.cur[tid];
+  if (tid == 0) bb.used1[g] = min(L.sp.arena_used, gm.A1);
   for (int o = 32; o > 0; o >>= 1) n_ins += __shfl_down(n_ins, o);
   if (lane_id() == 0 && n_ins) atomicAdd((unsigned long long *)&ctrs[CTR_INSERTED], (unsigned long long)n_ins);
 }
@@ -255,13 +324,9 @@ __global__ __launch_bounds__(WGB) void kc_l1_records_kernel(const uint64_t *recs
   constexpr int RPOS = Rnd<NL>::RPOS;
   const int tid = threadIdx.x;
   const uint32_t g = (blockIdx.x + rot) % gm.G, P1 = gm.P1;
-  if ((uint32_t)tid < P1) {
-    L.sp.cur[tid] = bb.cnt1[(size_t)g * P1 + tid];
-    L.sp.hist[0][tid] = 0;
-    L.sp.hist[1][tid] = 0;
-  }
+  const ChainDest D = l1_dest<NL>(gm, bb, g);
+  split_load_state(L.sp, P1, bb.cnt1 + (size_t)g * P1, D.chain, D.LMAX, D.log2CH, 0, bb.used1[g]);
   __syncthreads();
-  uint64_t *seg0 = bb.rec1 + (size_t)g * P1 * gm.C1 * NL;
   const uint64_t per_round = (uint64_t)WGB * RPOS;
   const uint64_t nrounds = (n + per_round - 1) / per_round;
   uint32_t n_ins = 0;
@@ -284,22 +349,50 @@ __global__ __launch_bounds__(WGB) void kc_l1_records_kernel(const uint64_t *recs
     }
     __syncthreads();
     split_round<NL, RPOS>(
-        L.sp, sorted, buf, P1, rec, br, gm.C1, [&](uint32_t b) { return seg0 + (size_t)b * gm.C1 * NL; },
-        [&](uint64_t h) { return hash_b1(h, gm); },
-        [&](uint32_t, const uint64_t (&r)[NL]) {
-          const uint64_t o = atomicAdd((unsigned long long *)&cb[CB_OVF1], 1ULL);
-          if (o < bb.ovf1_cap) {
-#pragma unroll
-            for (int w = 0; w < NL; w++) bb.ovf1[o * NL + w] = r[w];
-          } else {
-            cb[CB_FATAL] = 1;
-          }
-        });
+        L.sp, sorted, buf, P1, rec, br, D, [&](uint64_t h) { return hash_b1(h, gm); },
+        [&](uint32_t, const uint64_t (&r)[NL]) { l1_overflow<NL>(bb, cb, r); });
     buf ^= 1;
   }
   if ((uint32_t)tid < P1) bb.cnt1[(size_t)g * P1 + tid] = L.sp.cur[tid];
+  if (tid == 0) bb.used1[g] = min(L.sp.arena_used, gm.A1);
   for (int o = 32; o > 0; o >>= 1) n_ins += __shfl_down(n_ins, o);
-  if (lane_id() == 0 && n_ins) atomicAdd((unsigned long long *)&ctrs[CTR_INSERTED], (unsigned long long)n_ins);
+  if (lane_id() == 0 && n_ins) {
+    atomicAdd((unsigned long long *)&ctrs[CTR_INSERTED], (unsigned long long)n_ins);
+    atomicAdd((unsigned long long *)&ctrs[CTR_EXPECT], (unsigned long long)n_ins);
+  }
+}
+
+// record i of the (writer g, bucket b) chain
+template <int NL>
+__device__ __forceinline__ const uint64_t *l1_record(const Geom &gm, const BucketBufs &bb, uint32_t g, uint32_t b, uint32_t i) {
+  const uint32_t chunk = bb.chain1[((size_t)g * gm.P1 + b) * gm.L1MAX + (i >> gm.log2CH1)];
+  return bb.rec1 + (((((size_t)g * gm.A1) + chunk) << gm.log2CH1) + (i & ((1u << gm.log2CH1) - 1u))) * NL;
+}
+
+// record i of region r's chain
+template <int NL>
+__device__ __forceinline__ const uint64_t *l2_record(const Geom &gm, const BucketBufs &bb, size_t r, uint32_t i) {
+  const uint32_t chunk = bb.chain2[r * gm.L2MAX + (i >> gm.log2CH2)];
+  return bb.rec2 + (((size_t)chunk << gm.log2CH2) + (i & ((1u << gm.log2CH2) - 1u))) * NL;
+}
+
+// ---- between the levels: every bucket gets a private, exactly sized part of the level-2 arena ---------
+// chunks(b) = ceil(records(b) / CH2) + P2: each of its P2 regions wastes less than one chunk
+__global__ __launch_bounds__(WGB) void kc_bucket_prefix_kernel(Geom gm, BucketBufs bb, uint64_t *cb) {
+  __shared__ ScanLDS S;
+  const uint32_t b = threadIdx.x;
+  uint32_t chunks = 0;
+  if (b < gm.P1) {
+    uint64_t n = 0;
+    for (uint32_t g = 0; g < gm.G; g++) n += bb.cnt1[(size_t)g * gm.P1 + b];
+    chunks = (uint32_t)((n + (1u << gm.log2CH2) - 1) >> gm.log2CH2) + gm.P2;
+  }
+  const uint32_t e = block_excl_scan(chunks, S);
+  if (b < gm.P1) bb.base2[b] = e;
+  if (b == 0) {
+    bb.base2[gm.P1] = S.total;
+    if (S.total > gm.A2) cb[CB_FATAL] = 2;  // cannot happen while the host keeps the buffered records within its capacity
+  }
 }
 
 // ---- level 2 ------------------------------------------------------------------------------------------
@@ -323,15 +416,17 @@ __global__ __launch_bounds__(WGB) void kc_l2_split_kernel(Geom gm, BucketBufs bb
       const uint32_t e = block_excl_scan(v, L.sp.scan);
       if ((uint32_t)tid < G) L.pre[tid] = e;
       if (tid == 0) L.pre[G] = L.sp.scan.total;
-      if ((uint32_t)tid < P2) {
-        L.sp.cur[tid] = 0;
-        L.sp.hist[0][tid] = 0;
-        L.sp.hist[1][tid] = 0;
-      }
     }
+    ChainDest D;
+    D.arena = bb.rec2;
+    D.chain = bb.chain2 + (size_t)b1 * P2 * gm.L2MAX;
+    D.log2CH = gm.log2CH2;
+    D.LMAX = gm.L2MAX;
+    D.arena_base = bb.base2[b1];
+    D.arena_cap = bb.base2[b1 + 1] - bb.base2[b1];
+    split_load_state(L.sp, P2, nullptr, D.chain, D.LMAX, D.log2CH, D.arena_base, 0);
     __syncthreads();
     const uint32_t n = L.pre[G];
-    uint64_t *reg0 = bb.rec2 + (size_t)b1 * P2 * gm.C2 * NL;
     const uint32_t per_round = WGB * RPOS;
     uint32_t p = 0;  // segment cursor of this thread (its indices only grow)
     int buf = 0;
@@ -344,7 +439,7 @@ __global__ __launch_bounds__(WGB) void kc_l2_split_kernel(Geom gm, BucketBufs bb
         br[j] = ~0u;
         if (e < n) {
           while (e >= L.pre[p + 1]) p++;
-          const uint64_t *src = bb.rec1 + (((size_t)p * P1 + b1) * gm.C1 + (e - L.pre[p])) * NL;
+          const uint64_t *src = l1_record<NL>(gm, bb, p, b1, e - L.pre[p]);
 #pragma unroll
           for (int w = 0; w < NL; w++) rec[j][w] = src[w];
           const uint32_t b = hash_b2(rec_hash<NL>(rec[j]), gm);
@@ -354,8 +449,7 @@ __global__ __launch_bounds__(WGB) void kc_l2_split_kernel(Geom gm, BucketBufs bb
       }
       __syncthreads();
       split_round<NL, RPOS>(
-          L.sp, sorted, buf, P2, rec, br, gm.C2, [&](uint32_t b) { return reg0 + (size_t)b * gm.C2 * NL; },
-          [&](uint64_t h) { return hash_b2(h, gm); },
+          L.sp, sorted, buf, P2, rec, br, D, [&](uint64_t h) { return hash_b2(h, gm); },
           [&](uint32_t b, const uint64_t (&r)[NL]) {
             bb.flag[(size_t)b1 * P2 + b] = 1;
             const uint64_t o = atomicAdd((unsigned long long *)&cb[CB_OVF2], 1ULL);
@@ -373,7 +467,8 @@ __global__ __launch_bounds__(WGB) void kc_l2_split_kernel(Geom gm, BucketBufs bb
   }
 }
 
-// level-1 overflow records find their region with one atomic each (rare path)
+// level-1 overflow records have no region yet (rare path): they join the flagged regions' overflow list and
+// their region is flagged, so the region is handled whole by the global table
 template <int NL>
 __global__ void kc_ovf1_to_regions_kernel(Geom gm, BucketBufs bb, uint64_t n, uint64_t *cb) {
   const uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
@@ -382,19 +477,12 @@ __global__ void kc_ovf1_to_regions_kernel(Geom gm, BucketBufs bb, uint64_t n, ui
   for (int w = 0; w < NL; w++) r[w] = bb.ovf1[i * NL + w];
   const uint64_t h = rec_hash<NL>(r);
   const size_t reg = (size_t)hash_b1(h, gm) * gm.P2 + hash_b2(h, gm);
-  const uint32_t idx = atomicAdd(&bb.cnt2[reg], 1u);
-  if (idx < gm.C2) {
-    uint64_t *d = bb.rec2 + (reg * gm.C2 + idx) * NL;
-    for (int w = 0; w < NL; w++) d[w] = r[w];
+  bb.flag[reg] = 1;
+  const uint64_t o = atomicAdd((unsigned long long *)&cb[CB_OVF2], 1ULL);
+  if (o < bb.ovf2_cap) {
+    for (int w = 0; w < NL; w++) bb.ovf2[o * NL + w] = r[w];
   } else {
-    atomicSub(&bb.cnt2[reg], 1u);  // cnt2 stays the number of records stored in the array
-    bb.flag[reg] = 1;
-    const uint64_t o = atomicAdd((unsigned long long *)&cb[CB_OVF2], 1ULL);
-    if (o < bb.ovf2_cap) {
-      for (int w = 0; w < NL; w++) bb.ovf2[o * NL + w] = r[w];
-    } else {
-      cb[CB_FATAL] = 1;
-    }
+    cb[CB_FATAL] = 1;
   }
 }
 
@@ -493,11 +581,11 @@ __global__ __launch_bounds__(WGB) void kc_count_kernel(Geom gm, BucketBufs bb, O
       T.sum = 0;
     }
     __syncthreads();
-    const uint64_t *src = bb.rec2 + r * gm.C2 * NL;
     for (uint32_t i = tid; i < n; i += WGB) {
+      const uint64_t *src = l2_record<NL>(gm, bb, r, i);
       uint64_t rec[NL];
 #pragma unroll
-      for (int w = 0; w < NL; w++) rec[w] = src[(size_t)i * NL + w];
+      for (int w = 0; w < NL; w++) rec[w] = src[w];
       lds_insert<NL>(T, S, rec);
     }
     __syncthreads();
@@ -571,10 +659,10 @@ __global__ __launch_bounds__(TPB) void kc_flagged_to_table_kernel(Geom gm, Bucke
   for (size_t r = blockIdx.x; r < R; r += gridDim.x) {
     if (!bb.flag[r]) continue;
     const uint32_t n = bb.cnt2[r];
-    const uint64_t *src = bb.rec2 + r * gm.C2 * NL;
     for (uint32_t i = threadIdx.x; i < n; i += TPB) {
+      const uint64_t *src = l2_record<NL>(gm, bb, r, i);
       uint64_t rec[NL];
-      for (int w = 0; w < NL; w++) rec[w] = src[(size_t)i * NL + w];
+      for (int w = 0; w < NL; w++) rec[w] = src[w];
       table_insert<NL>(t, rec, ctrs);
     }
   }
@@ -587,10 +675,11 @@ __global__ __launch_bounds__(TPB) void kc_l1_to_table_kernel(Geom gm, BucketBufs
   const size_t nseg = (size_t)gm.G * gm.P1;
   for (size_t sgi = blockIdx.x; sgi < nseg; sgi += gridDim.x) {
     const uint32_t n = bb.cnt1[sgi];
-    const uint64_t *src = bb.rec1 + sgi * gm.C1 * NL;
+    const uint32_t g = (uint32_t)(sgi / gm.P1), b = (uint32_t)(sgi % gm.P1);
     for (uint32_t i = threadIdx.x; i < n; i += TPB) {
+      const uint64_t *src = l1_record<NL>(gm, bb, g, b, i);
       uint64_t rec[NL];
-      for (int w = 0; w < NL; w++) rec[w] = src[(size_t)i * NL + w];
+      for (int w = 0; w < NL; w++) rec[w] = src[w];
       table_insert<NL>(t, rec, ctrs);
     }
   }

@@ -44,6 +44,7 @@ enum {
   CTR_PURGED,
   CTR_SUM_COUNTS,
   CTR_RAW_KMERS,
+  CTR_EXPECT,        // k-mer occurrences with two neighbours submitted so far (upper bound of what is buffered)
   CTR_OVERFLOW,      // bin mode: a segment was too small
   CTR_BIN0,          // [CTR_BIN0 + d]: records binned for shard d (64 slots)
   CTR_COUNT = CTR_BIN0 + 64
@@ -376,20 +377,25 @@ __global__ void kc_tile_first_kernel(const uint64_t *offsets, uint64_t nreads, u
 
 // raw k-mers of the block: sum over reads of max(0, len-k+1) (kcount.cpp:78,86)
 __global__ void kc_read_stats_kernel(const uint64_t *offsets, uint64_t nreads, int k, uint64_t *ctrs) {
-  uint64_t acc = 0;
+  uint64_t acc = 0, exp = 0;
   const uint64_t stride = (uint64_t)gridDim.x * blockDim.x;
   for (uint64_t r = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x; r < nreads; r += stride) {
     uint64_t len = offsets[r + 1] - offsets[r];
     if (len >= (uint64_t)k) acc += len - k + 1;
+    if (len >= (uint64_t)k + 2) exp += len - k - 1;
   }
-  for (int o = 32; o > 0; o >>= 1) acc += __shfl_down(acc, o);
+  for (int o = 32; o > 0; o >>= 1) {
+    acc += __shfl_down(acc, o);
+    exp += __shfl_down(exp, o);
+  }
   if (lane_id() == 0 && acc) atomicAdd((unsigned long long *)&ctrs[CTR_RAW_KMERS], (unsigned long long)acc);
+  if (lane_id() == 0 && exp) atomicAdd((unsigned long long *)&ctrs[CTR_EXPECT], (unsigned long long)exp);
 }
 
 // the same for a '_'-joined block: count runs of non-separator bytes
 __global__ void kc_seqblock_stats_kernel(const uint8_t *seqs, uint64_t len, int k, uint64_t *ctrs) {
   // one thread per byte that ends a run (next byte is '_' or end): walks back to the run start
-  uint64_t acc = 0;
+  uint64_t acc = 0, exp = 0;
   const uint64_t stride = (uint64_t)gridDim.x * blockDim.x;
   for (uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x; i < len; i += stride) {
     if (seqs[i] == '_') continue;
@@ -398,9 +404,14 @@ __global__ void kc_seqblock_stats_kernel(const uint8_t *seqs, uint64_t len, int 
     while (j > 0 && seqs[j - 1] != '_') j--;
     uint64_t rl = i - j + 1;
     if (rl >= (uint64_t)k) acc += rl - k + 1;
+    if (rl >= (uint64_t)k + 2) exp += rl - k - 1;
   }
-  for (int o = 32; o > 0; o >>= 1) acc += __shfl_down(acc, o);
+  for (int o = 32; o > 0; o >>= 1) {
+    acc += __shfl_down(acc, o);
+    exp += __shfl_down(exp, o);
+  }
   if (lane_id() == 0 && acc) atomicAdd((unsigned long long *)&ctrs[CTR_RAW_KMERS], (unsigned long long)acc);
+  if (lane_id() == 0 && exp) atomicAdd((unsigned long long *)&ctrs[CTR_EXPECT], (unsigned long long)exp);
 }
 
 // ---- finalize ----------------------------------------------------------------------------------

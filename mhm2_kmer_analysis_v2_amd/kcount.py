@@ -72,7 +72,7 @@ class KmerCounter:
 
     def set_tuning(self, **kw):
         """Geometry overrides of the bucketed path (tests / tuning): mode, writers, p1, p2, slots,
-        seg_capacity, reg_capacity, ovf_capacity."""
+        chunk1, chunk2, chain1_max, chain2_max, arena1, ovf_capacity."""
         t = kc_tuning()
         for k, v in kw.items():
             if not hasattr(t, k):

@@ -302,11 +302,13 @@ def _reads_for_overflow(seed=21, n=1200):
 
 @pytest.mark.parametrize("k", [21, 51])
 @pytest.mark.parametrize("tuning", [
-    dict(writers=2, p1=2, p2=4, slots=4096, seg_capacity=200, ovf_capacity=1 << 20),   # level-1 segments overflow
-    dict(writers=2, p1=2, p2=4, slots=4096, reg_capacity=300, ovf_capacity=1 << 20),   # region arrays overflow
-    dict(writers=2, p1=2, p2=4, slots=64),                                             # more distinct k-mers than LDS slots
-    dict(writers=4, p1=8, p2=8, slots=128, seg_capacity=150, reg_capacity=400, ovf_capacity=1 << 20),  # all at once
-], ids=["seg-overflow", "region-overflow", "lds-full", "everything"])
+    dict(writers=2, p1=2, p2=4, slots=4096, chunk1=16, chain1_max=8, ovf_capacity=1 << 20),   # level-1 chains overflow
+    dict(writers=2, p1=2, p2=4, slots=4096, chunk1=16, arena1=20, ovf_capacity=1 << 20),      # a writer's arena runs out
+    dict(writers=2, p1=2, p2=4, slots=4096, chunk2=16, chain2_max=10, ovf_capacity=1 << 20),  # region chains overflow
+    dict(writers=2, p1=2, p2=4, slots=64),                                                    # more distinct k-mers than LDS slots
+    dict(writers=3, p1=4, p2=8, slots=4096, chunk1=16, chunk2=16),                            # many chunks per chain, nothing overflows
+    dict(writers=4, p1=8, p2=8, slots=128, chunk1=16, chain1_max=6, chunk2=16, chain2_max=12, ovf_capacity=1 << 20),  # all at once
+], ids=["chain1-overflow", "arena1-exhausted", "chain2-overflow", "lds-full", "many-chunks", "everything"])
 def test_overflow_paths_are_exact(k, tuning):
     reads, quals = _reads_for_overflow(21 + k)
     b, q, offs = arrays(reads, quals)
@@ -324,7 +326,7 @@ def test_overflow_paths_are_exact(k, tuning):
 def test_exhausted_overflow_list_is_an_error_not_a_loss():
     reads, quals = _reads_for_overflow()
     b, q, offs = arrays(reads, quals)
-    with pkg.KmerCounter(21, tuning=dict(writers=2, p1=2, p2=4, seg_capacity=100, ovf_capacity=50)) as kc:
+    with pkg.KmerCounter(21, tuning=dict(writers=2, p1=2, p2=4, chunk1=16, chain1_max=4, ovf_capacity=50)) as kc:
         with pytest.raises(pkg.KcError) as e:
             kc.submit_reads(b, q, offs)
             kc.results()

@@ -456,7 +456,7 @@ static int bk_init(kc_ctx *c) {
   const uint64_t CH1 = 1ULL << g.log2CH1, CH2 = 1ULL << g.log2CH2;
   // chains may grow to several times the mean: k-mer multiplicities are heavy-tailed
   g.L1MAX = t.chain1_max ? t.chain1_max : (uint32_t)(4.0 * mean1 / (double)CH1) + 8;
-  g.L2MAX = t.chain2_max ? t.chain2_max : (uint32_t)(4.0 * mean2 / (double)CH2) + 8;
+  g.L2MAX = std::min<uint32_t>(CHAIN_LDS, t.chain2_max ? t.chain2_max : (uint32_t)(4.0 * mean2 / (double)CH2) + 8);
   g.A1 = t.arena1 ? t.arena1 : (uint32_t)(1.03 * (double)bcap / ((double)g.G * (double)CH1)) + g.P1 + 16;
   const uint64_t a2 = bcap / CH2 + R + g.P1 + 16;
   if (a2 >= (1ULL << 32) || (uint64_t)g.A1 * g.G >= (1ULL << 32) || bcap / g.P1 >= (1ULL << 31)) return KC_ERR_INVALID_ARG;
@@ -1015,7 +1015,7 @@ static int bk_count_t(kc_ctx *c, const OutBufs &ob) {
   const uint64_t R = (uint64_t)c->gm.P1 * c->gm.P2;
   KernelTimer kt(c, KT_COUNT_REGIONS);
   hipLaunchKernelGGL(kern, dim3((unsigned)std::min<uint64_t>(R, (uint64_t)c->num_cus)), dim3(WGB), sizeof(CountLDS<NL>), c->stream, c->gm, c->bb,
-                     ob, c->cfg.dmin_thres, c->d_ctrs, c->d_cb);
+                     ob, c->cfg.dmin_thres, c->d_ctrs, c->d_cb, (uint32_t)(getenv("KC_DEBUG_COUNT") ? atoi(getenv("KC_DEBUG_COUNT")) : 0));
   return KC_OK;
 }
 

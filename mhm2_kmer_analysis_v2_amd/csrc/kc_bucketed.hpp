@@ -88,6 +88,10 @@ __device__ __forceinline__ uint64_t rec_hash(const uint64_t (&rec)[NL]) {
   return kc_hash<NL>(key);
 }
 
+// Barrier for data exchanged through LDS only.  __syncthreads() also drains the vector-memory counter,
+// which would serialise the global loads these kernels keep in flight across their LDS phases.
+__device__ __forceinline__ void lds_barrier() { asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory"); }
+
 // ---- workgroup exclusive scan over WGB values --------------------------------------------------
 struct ScanLDS {
   uint32_t wsum[32];
@@ -109,14 +113,14 @@ __device__ __forceinline__ uint32_t block_excl_scan(uint32_t v, ScanLDS &S) {
   const int tid = threadIdx.x, wave = tid >> 6;
   const uint32_t incl = wave_incl_scan(v);
   if (lane_id() == 63) S.wsum[wave] = incl;
-  __syncthreads();
+  lds_barrier();
   if (tid < 64) {
     const uint32_t w = (tid < WGB / 64) ? S.wsum[tid] : 0;
     const uint32_t wi = wave_incl_scan(w);
     if (tid < 32) S.wpre[tid] = wi - w;
     if (tid == WGB / 64 - 1) S.total = wi;
   }
-  __syncthreads();
+  lds_barrier();
   return incl - v + S.wpre[wave];
 }
 
@@ -126,9 +130,8 @@ struct SplitLDS {
   uint32_t hist[2][PMAX];  // per-bucket counts of this round (double-buffered); becomes "fit" after the scan
   uint32_t offs[PMAX];     // exclusive prefix: where the bucket's run starts in the sorted staging
   uint32_t dbase[PMAX];    // position in the destination chain where the run starts
-  uint32_t cur[PMAX];      // records in each destination chain owned by this workgroup
-  uint32_t c0[PMAX];       // chunk that holds position dbase
-  uint32_t last[PMAX];     // last chunk of the chain
+  uint32_t c0[PMAX];       // chunk that holds position dbase when the run starts inside an old chunk
+  uint32_t nb[PMAX];       // chunk index ci >= first new one lives in chunk nb + ci (new chunks of a round are consecutive)
   uint32_t arena_used;     // chunks taken from the owner's arena
   ScanLDS scan;
 };
@@ -142,12 +145,19 @@ struct ChainDest {
   uint32_t arena_base;  // id of the owner's first chunk
 };
 
+// state of destination `tid`, kept in thread tid's registers (only that thread ever touches it)
+struct ChainState {
+  uint32_t cur;   // records in the chain
+  uint32_t last;  // id of its last chunk (valid when cur is not chunk-aligned)
+};
+
 // Phase 2-4 of a round: scan, reserve, scatter to LDS, copy out.  The caller has already bumped
 // hist[buf] with LDS atomics (bucket | rank<<10 in br[], ~0 for "no record") and hit a barrier.
 //   bucket_of(hash) recomputes a record's bucket during copy-out; overflow(b, rec) takes what found no room
 template <int NL, int R, class BucketFn, class OvfFn>
 __device__ __forceinline__ void split_round(SplitLDS &L, uint64_t *sorted, int buf, uint32_t P, const uint64_t (&rec)[R][NL],
-                                            const uint32_t (&br)[R], const ChainDest &D, BucketFn bucket_of, OvfFn overflow) {
+                                            const uint32_t (&br)[R], const ChainDest &D, ChainState &st, BucketFn bucket_of,
+                                            OvfFn overflow) {
   const int tid = threadIdx.x;
   uint32_t *H = L.hist[buf];
   const uint32_t v = ((uint32_t)tid < P) ? H[tid] : 0u;
@@ -155,7 +165,7 @@ __device__ __forceinline__ void split_round(SplitLDS &L, uint64_t *sorted, int b
   const uint32_t CHm = (1u << D.log2CH) - 1u;
   if ((uint32_t)tid < P) {
     L.offs[tid] = excl;
-    const uint32_t base = L.cur[tid];
+    const uint32_t base = st.cur;
     uint32_t fit = v;
     const uint64_t room = ((uint64_t)D.LMAX << D.log2CH) - base;  // the chain holds at most LMAX chunks
     if ((uint64_t)fit > room) fit = (uint32_t)room;
@@ -171,14 +181,15 @@ __device__ __forceinline__ void split_round(SplitLDS &L, uint64_t *sorted, int b
       uint32_t *ch = D.chain + (size_t)tid * D.LMAX + have;
       for (uint32_t i = 0; i < k; i++) ch[i] = D.arena_base + a + i;
     }
-    L.c0[tid] = (base & CHm) ? L.last[tid] : D.arena_base + a;  // only read when fit > 0, and then k > 0 if base is chunk-aligned
-    if (k) L.last[tid] = D.arena_base + a + k - 1;
+    L.c0[tid] = st.last;
+    L.nb[tid] = D.arena_base + a - have;  // unsigned wrap is fine: only used as nb + ci with ci >= have
+    if (k) st.last = D.arena_base + a + k - 1;
     L.dbase[tid] = base;
     H[tid] = fit;
-    L.cur[tid] = base + fit;
+    st.cur = base + fit;
     L.hist[buf ^ 1][tid] = 0;  // next round's histogram
   }
-  __syncthreads();
+  lds_barrier();
   const uint32_t total = L.scan.total;
 #pragma unroll
   for (int j = 0; j < R; j++) {
@@ -189,7 +200,7 @@ __device__ __forceinline__ void split_round(SplitLDS &L, uint64_t *sorted, int b
       for (int w = 0; w < NL; w++) sorted[(size_t)pos * NL + w] = rec[j][w];
     }
   }
-  __syncthreads();
+  lds_barrier();
   for (uint32_t i = tid; i < total; i += WGB) {
     uint64_t r[NL];
 #pragma unroll
@@ -197,11 +208,9 @@ __device__ __forceinline__ void split_round(SplitLDS &L, uint64_t *sorted, int b
     const uint32_t b = bucket_of(rec_hash<NL>(r));
     const uint32_t j = i - L.offs[b];
     if (j < H[b]) {
-      const uint32_t p = L.dbase[b] + j, ci = p >> D.log2CH;
-      // runs are short against a chunk: nearly always the chunk the run starts in
-      const uint32_t cid = (ci == (L.dbase[b] >> D.log2CH))
-                               ? L.c0[b]
-                               : __hip_atomic_load(&D.chain[(size_t)b * D.LMAX + ci], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      const uint32_t db = L.dbase[b], p = db + j, ci = p >> D.log2CH;
+      // the run starts inside the chain's old last chunk (c0) unless it starts chunk-aligned; later chunks are new
+      const uint32_t cid = ((db & CHm) && ci == (db >> D.log2CH)) ? L.c0[b] : L.nb[b] + ci;
       uint64_t *d = D.arena + (((size_t)cid << D.log2CH) + (p & CHm)) * NL;
 #pragma unroll
       for (int w = 0; w < NL; w++) d[w] = r[w];
@@ -209,22 +218,26 @@ __device__ __forceinline__ void split_round(SplitLDS &L, uint64_t *sorted, int b
       overflow(b, r);
     }
   }
-  __syncthreads();
+  lds_barrier();
 }
 
 // load the persistent state of this owner's P chains (before its first round)
-__device__ __forceinline__ void split_load_state(SplitLDS &L, uint32_t P, const uint32_t *cnt, const uint32_t *chain, uint32_t LMAX,
-                                                 uint32_t log2CH, uint32_t arena_base, uint32_t used) {
+__device__ __forceinline__ ChainState split_load_state(SplitLDS &L, uint32_t P, const uint32_t *cnt, const uint32_t *chain,
+                                                       uint32_t LMAX, uint32_t log2CH, uint32_t chain_id_base, uint32_t used) {
   const int tid = threadIdx.x;
+  ChainState st;
+  st.cur = 0;
+  st.last = 0;
   if ((uint32_t)tid < P) {
     const uint32_t c = cnt ? cnt[tid] : 0u;
-    L.cur[tid] = c;
-    L.last[tid] = (c & ((1u << log2CH) - 1u)) ? chain[(size_t)tid * LMAX + (c >> log2CH)] : 0u;
+    st.cur = c;
+    if (c & ((1u << log2CH) - 1u)) st.last = chain[(size_t)tid * LMAX + (c >> log2CH)];
     L.hist[0][tid] = 0;
     L.hist[1][tid] = 0;
   }
   if (tid == 0) L.arena_used = used;
-  (void)arena_base;
+  (void)chain_id_base;
+  return st;
 }
 
 // ---- level 1 from reads ---------------------------------------------------------------------------
@@ -267,7 +280,7 @@ __global__ __launch_bounds__(WGB) void kc_l1_reads_kernel(ExtractArgs a, Geom gm
   // writer id: launches rotate their first writer (rot) so that many small submits still spread evenly
   const uint32_t g = (blockIdx.x + rot) % gm.G, P1 = gm.P1;
   const ChainDest D = l1_dest<NL>(gm, bb, g);
-  split_load_state(L.sp, P1, bb.cnt1 + (size_t)g * P1, D.chain, D.LMAX, D.log2CH, 0, bb.used1[g]);
+  ChainState cst = split_load_state(L.sp, P1, bb.cnt1 + (size_t)g * P1, D.chain, D.LMAX, D.log2CH, 0, bb.used1[g]);
   __syncthreads();
   const int64_t lo = a.align, hi = (int64_t)a.align + (int64_t)a.total;
   const uint64_t nsuper = (ntiles + QUARTERS - 1) / QUARTERS;
@@ -297,14 +310,14 @@ __global__ __launch_bounds__(WGB) void kc_l1_reads_kernel(ExtractArgs a, Geom gm
           n_ins++;
         }
       }
-      __syncthreads();
+      lds_barrier();
       split_round<NL, RPOS>(
-          L.sp, sorted, buf, P1, rec, br, D, [&](uint64_t h) { return hash_b1(h, gm); },
+          L.sp, sorted, buf, P1, rec, br, D, cst, [&](uint64_t h) { return hash_b1(h, gm); },
           [&](uint32_t, const uint64_t (&r)[NL]) { l1_overflow<NL>(bb, cb, r); });
       buf ^= 1;
     }
   }
-  if ((uint32_t)tid < P1) bb.cnt1[(size_t)g * P1 + tid] = L.sp.cur[tid];
+  if ((uint32_t)tid < P1) bb.cnt1[(size_t)g * P1 + tid] = cst.cur;
   if (tid == 0) bb.used1[g] = min(L.sp.arena_used, gm.A1);
   for (int o = 32; o > 0; o >>= 1) n_ins += __shfl_down(n_ins, o);
   if (lane_id() == 0 && n_ins) atomicAdd((unsigned long long *)&ctrs[CTR_INSERTED], (unsigned long long)n_ins);
@@ -325,7 +338,7 @@ __global__ __launch_bounds__(WGB) void kc_l1_records_kernel(const uint64_t *recs
   const int tid = threadIdx.x;
   const uint32_t g = (blockIdx.x + rot) % gm.G, P1 = gm.P1;
   const ChainDest D = l1_dest<NL>(gm, bb, g);
-  split_load_state(L.sp, P1, bb.cnt1 + (size_t)g * P1, D.chain, D.LMAX, D.log2CH, 0, bb.used1[g]);
+  ChainState cst = split_load_state(L.sp, P1, bb.cnt1 + (size_t)g * P1, D.chain, D.LMAX, D.log2CH, 0, bb.used1[g]);
   __syncthreads();
   const uint64_t per_round = (uint64_t)WGB * RPOS;
   const uint64_t nrounds = (n + per_round - 1) / per_round;
@@ -347,13 +360,13 @@ __global__ __launch_bounds__(WGB) void kc_l1_records_kernel(const uint64_t *recs
         n_ins++;
       }
     }
-    __syncthreads();
+    lds_barrier();
     split_round<NL, RPOS>(
-        L.sp, sorted, buf, P1, rec, br, D, [&](uint64_t h) { return hash_b1(h, gm); },
+        L.sp, sorted, buf, P1, rec, br, D, cst, [&](uint64_t h) { return hash_b1(h, gm); },
         [&](uint32_t, const uint64_t (&r)[NL]) { l1_overflow<NL>(bb, cb, r); });
     buf ^= 1;
   }
-  if ((uint32_t)tid < P1) bb.cnt1[(size_t)g * P1 + tid] = L.sp.cur[tid];
+  if ((uint32_t)tid < P1) bb.cnt1[(size_t)g * P1 + tid] = cst.cur;
   if (tid == 0) bb.used1[g] = min(L.sp.arena_used, gm.A1);
   for (int o = 32; o > 0; o >>= 1) n_ins += __shfl_down(n_ins, o);
   if (lane_id() == 0 && n_ins) {
@@ -424,32 +437,48 @@ __global__ __launch_bounds__(WGB) void kc_l2_split_kernel(Geom gm, BucketBufs bb
     D.LMAX = gm.L2MAX;
     D.arena_base = bb.base2[b1];
     D.arena_cap = bb.base2[b1 + 1] - bb.base2[b1];
-    split_load_state(L.sp, P2, nullptr, D.chain, D.LMAX, D.log2CH, D.arena_base, 0);
+    ChainState cst = split_load_state(L.sp, P2, nullptr, D.chain, D.LMAX, D.log2CH, D.arena_base, 0);
     __syncthreads();
     const uint32_t n = L.pre[G];
     const uint32_t per_round = WGB * RPOS;
     uint32_t p = 0;  // segment cursor of this thread (its indices only grow)
+    // the records of the next round are already on their way while this round is split
+    uint64_t nxt[RPOS][NL];
+    auto load_round = [&](uint32_t v0) {
+#pragma unroll
+      for (int j = 0; j < RPOS; j++) {
+        const uint32_t e = v0 + (uint32_t)j * WGB + tid;
+        if (e < n) {
+          while (e >= L.pre[p + 1]) p++;
+          const uint64_t *src = l1_record<NL>(gm, bb, p, b1, e - L.pre[p]);
+#pragma unroll
+          for (int w = 0; w < NL; w++) nxt[j][w] = src[w];
+        }
+      }
+    };
+    load_round(0);
     int buf = 0;
     for (uint32_t v0 = 0; v0 < n; v0 += per_round) {
       uint64_t rec[RPOS][NL];
       uint32_t br[RPOS];
 #pragma unroll
+      for (int j = 0; j < RPOS; j++)
+#pragma unroll
+        for (int w = 0; w < NL; w++) rec[j][w] = nxt[j][w];
+      if (v0 + per_round < n) load_round(v0 + per_round);
+#pragma unroll
       for (int j = 0; j < RPOS; j++) {
         const uint32_t e = v0 + (uint32_t)j * WGB + tid;
         br[j] = ~0u;
         if (e < n) {
-          while (e >= L.pre[p + 1]) p++;
-          const uint64_t *src = l1_record<NL>(gm, bb, p, b1, e - L.pre[p]);
-#pragma unroll
-          for (int w = 0; w < NL; w++) rec[j][w] = src[w];
           const uint32_t b = hash_b2(rec_hash<NL>(rec[j]), gm);
           const uint32_t rank = atomicAdd(&L.sp.hist[buf][b], 1u);
           br[j] = b | (rank << 10);
         }
       }
-      __syncthreads();
+      lds_barrier();
       split_round<NL, RPOS>(
-          L.sp, sorted, buf, P2, rec, br, D, [&](uint64_t h) { return hash_b2(h, gm); },
+          L.sp, sorted, buf, P2, rec, br, D, cst, [&](uint64_t h) { return hash_b2(h, gm); },
           [&](uint32_t b, const uint64_t (&r)[NL]) {
             bb.flag[(size_t)b1 * P2 + b] = 1;
             const uint64_t o = atomicAdd((unsigned long long *)&cb[CB_OVF2], 1ULL);
@@ -462,7 +491,7 @@ __global__ __launch_bounds__(WGB) void kc_l2_split_kernel(Geom gm, BucketBufs bb
           });
       buf ^= 1;
     }
-    if ((uint32_t)tid < P2) bb.cnt2[(size_t)b1 * P2 + tid] = L.sp.cur[tid];
+    if ((uint32_t)tid < P2) bb.cnt2[(size_t)b1 * P2 + tid] = cst.cur;
     __syncthreads();
   }
 }
@@ -487,13 +516,16 @@ __global__ void kc_ovf1_to_regions_kernel(Geom gm, BucketBufs bb, uint64_t n, ui
 }
 
 // ---- count: the LDS probe window ---------------------------------------------------------------------
+constexpr uint32_t CHAIN_LDS = 512;  // longest region chain (L2MAX) the count kernel can stage
+
 // LDS image of one region, structure-of-arrays so that neighbouring slots sit in neighbouring banks.
 template <int NL>
 struct CountLDS {
-  static constexpr uint32_t SMAX = (147456 - 64) / (8 * NL + 36);
+  static constexpr uint32_t SMAX = (147456 - 64 - 4 * CHAIN_LDS) / (8 * NL + 36);
   uint64_t keys[SMAX * NL];  // word w of slot s at keys[w*SMAX + s]; the LAST word is the claim word
   uint32_t cnt[SMAX];
   uint32_t ext[8 * SMAX];    // ext[e*SMAX + s]
+  uint32_t chain[CHAIN_LDS];  // the region's chunk ids
   uint32_t nout, nent, fail, gbase_lo, gbase_hi;
   unsigned long long sum;
 };
@@ -508,7 +540,7 @@ struct OutBufs {
 };
 
 template <int NL>
-__device__ __forceinline__ void lds_insert(CountLDS<NL> &T, uint32_t S, const uint64_t (&rec)[NL]) {
+__device__ __forceinline__ void lds_insert(CountLDS<NL> &T, uint32_t S, const uint64_t (&rec)[NL], uint32_t dbg = 0) {
   constexpr uint32_t SM = CountLDS<NL>::SMAX;
   uint64_t key[NL];
 #pragma unroll
@@ -529,7 +561,7 @@ __device__ __forceinline__ void lds_insert(CountLDS<NL> &T, uint32_t S, const ui
           __threadfence_block();
           atomicExch(&claim[s], (unsigned long long)key[NL - 1]);
         }
-        atomicAdd(&T.nent, 1u);
+        if (!(dbg & 8u)) atomicAdd(&T.nent, 1u);
         break;
       }
     }
@@ -548,16 +580,67 @@ __device__ __forceinline__ void lds_insert(CountLDS<NL> &T, uint32_t S, const ui
       return;
     }
   }
+  if (dbg & 16u) return;
   atomicAdd(&T.cnt[s], 1u);
+  if (dbg & 32u) return;
   if (le < 4u) atomicAdd(&T.ext[le * SM + s], 1u);
   if (re < 4u) atomicAdd(&T.ext[(4 + re) * SM + s], 1u);
+}
+
+// One-word keys: B records of a lane probe together.  Every probe is a single LDS compare-and-swap
+// (EMPTY -> key) whose return value tells "claimed", "already there" or "someone else": the B CAS of a
+// trip are issued back to back and waited for once, so the LDS round trips of the lock-stepped lanes
+// overlap instead of adding up (a wave leaves the loop only when its slowest lane has found its slot).
+template <int B>
+__device__ __forceinline__ void lds_insert_multi(CountLDS<1> &T, uint32_t S, const uint64_t (&rec)[B][1], const bool (&valid)[B]) {
+  constexpr uint32_t SM = CountLDS<1>::SMAX;
+  unsigned long long *claim = (unsigned long long *)&T.keys[0];
+  uint64_t key[B];
+  uint32_t s[B], probes = 0, nnew = 0;
+  bool act[B];
+#pragma unroll
+  for (int j = 0; j < B; j++) {
+    key[j] = rec[j][0] & ~KC_EXT_MASK;
+    uint64_t kk[1] = {key[j]};
+    s[j] = hash_slot(kc_hash<1>(kk), S);
+    act[j] = valid[j];
+  }
+  for (;;) {
+    bool any = false;
+#pragma unroll
+    for (int j = 0; j < B; j++) any |= act[j];
+    if (!any) break;
+    unsigned long long old[B];
+#pragma unroll
+    for (int j = 0; j < B; j++)
+      if (act[j]) old[j] = atomicCAS(&claim[s[j]], (unsigned long long)KEY_EMPTY, (unsigned long long)key[j]);
+#pragma unroll
+    for (int j = 0; j < B; j++) {
+      if (!act[j]) continue;
+      if (old[j] == KEY_EMPTY || old[j] == key[j]) {
+        nnew += (old[j] == KEY_EMPTY);
+        act[j] = false;
+        const uint32_t le = (uint32_t)(rec[j][0] & 7u), re = (uint32_t)((rec[j][0] >> 3) & 7u);
+        atomicAdd(&T.cnt[s[j]], 1u);
+        if (le < 4u) atomicAdd(&T.ext[le * SM + s[j]], 1u);
+        if (re < 4u) atomicAdd(&T.ext[(4 + re) * SM + s[j]], 1u);
+      } else {
+        s[j] = (s[j] + 1 == S) ? 0 : s[j] + 1;
+      }
+    }
+    if (++probes > S) {  // every slot holds some other k-mer
+      T.fail = 1;
+      break;
+    }
+  }
+  if (nnew) atomicAdd(&T.nent, nnew);
 }
 
 // DUMP = false: S7 vote + S8 purge, survivors to the result arrays.  DUMP = true: every entry with its raw
 // (clipped) counters, for tests of S5/S6; no statistics are touched.
 template <int NL, bool DUMP>
 __global__ __launch_bounds__(WGB) void kc_count_kernel(Geom gm, BucketBufs bb, OutBufs out, int dmin_thres, uint64_t *ctrs,
-                                                       uint64_t *cb) {
+                                                       uint64_t *cb, uint32_t dbg) {
   extern __shared__ __align__(16) uint8_t smem[];
   CountLDS<NL> &T = *reinterpret_cast<CountLDS<NL> *>(smem);
   constexpr uint32_t SM = CountLDS<NL>::SMAX;
@@ -567,6 +650,7 @@ __global__ __launch_bounds__(WGB) void kc_count_kernel(Geom gm, BucketBufs bb, O
   for (size_t r = blockIdx.x; r < R; r += gridDim.x) {
     const uint32_t n = bb.cnt2[r];
     if (n == 0 || bb.flag[r]) continue;  // uniform across the workgroup
+    if (!(dbg & 4u))
     for (uint32_t s = tid; s < S; s += WGB) {
 #pragma unroll
       for (int w = 0; w < NL; w++) T.keys[w * SM + s] = KEY_EMPTY;
@@ -580,13 +664,43 @@ __global__ __launch_bounds__(WGB) void kc_count_kernel(Geom gm, BucketBufs bb, O
       T.fail = 0;
       T.sum = 0;
     }
+    {
+      const uint32_t nch = (n + (1u << gm.log2CH2) - 1) >> gm.log2CH2;
+      if ((uint32_t)tid < nch) T.chain[tid] = bb.chain2[r * gm.L2MAX + tid];
+    }
     __syncthreads();
-    for (uint32_t i = tid; i < n; i += WGB) {
-      const uint64_t *src = l2_record<NL>(gm, bb, r, i);
-      uint64_t rec[NL];
+    // several independent loads in flight per thread before the dependent LDS work starts
+    constexpr int BATCH = NL == 1 ? 8 : NL == 2 ? 4 : 2;
+    const uint32_t CHm = (1u << gm.log2CH2) - 1u;
+    for (uint32_t i0 = 0; i0 < n; i0 += WGB * BATCH) {
+      uint64_t rec[BATCH][NL];
 #pragma unroll
-      for (int w = 0; w < NL; w++) rec[w] = src[w];
-      lds_insert<NL>(T, S, rec);
+      for (int j = 0; j < BATCH; j++) {
+        const uint32_t i = i0 + (uint32_t)j * WGB + tid;
+        if (i < n) {
+          const uint64_t *src = bb.rec2 + (((size_t)T.chain[i >> gm.log2CH2] << gm.log2CH2) + (i & CHm)) * NL;
+#pragma unroll
+          for (int w = 0; w < NL; w++) rec[j][w] = src[w];
+        }
+      }
+      if constexpr (NL == 1) {
+        bool valid[BATCH];
+#pragma unroll
+        for (int j = 0; j < BATCH; j++) valid[j] = (i0 + (uint32_t)j * WGB + tid) < n;
+        if (dbg & 1u) {
+#pragma unroll
+          for (int j = 0; j < BATCH; j++)
+            if (valid[j] && rec[j][0] == 0x123456789ULL) T.fail = 1;  // keep the loads alive
+        } else {
+          lds_insert_multi<BATCH>(T, S, rec, valid);
+        }
+      } else {
+#pragma unroll
+        for (int j = 0; j < BATCH; j++) {
+          const uint32_t i = i0 + (uint32_t)j * WGB + tid;
+          if (i < n) lds_insert<NL>(T, S, rec[j], dbg);
+        }
+      }
     }
     __syncthreads();
     if (T.fail) {  // more distinct k-mers than slots: the whole region goes to the global table instead
@@ -595,6 +709,10 @@ __global__ __launch_bounds__(WGB) void kc_count_kernel(Geom gm, BucketBufs bb, O
       continue;
     }
     // S7 vote + S8 purge; survivors get a rank
+    if (dbg & 2u) {
+      __syncthreads();
+      continue;
+    }
     for (uint32_t s = tid; s < S; s += WGB) {
       uint32_t packed = ~0u;
       if (T.keys[(NL - 1) * SM + s] != KEY_EMPTY) {

@@ -160,6 +160,9 @@ int kc_submit_seq_block(kc_ctx *ctx, const char *seqs, uint64_t len, int on_devi
 int kc_extract_partition(kc_ctx *ctx, const uint8_t *bases, const uint8_t *quals, const uint64_t *offsets,
                          uint64_t nreads, int on_device, uint64_t *d_records, uint64_t seg_capacity,
                          uint64_t *h_counts);
+/* The same for a '_'-joined, case-masked block (the format ParseAndPackGPUDriver::process_seq_block takes). */
+int kc_extract_partition_seq_block(kc_ctx *ctx, const char *seqs, uint64_t len, int on_device, uint64_t *d_records,
+                                   uint64_t seg_capacity, uint64_t *h_counts);
 /* Receiver side: HashTableGPUDriver::insert_supermer/insert_supermer_block
  * (gpu_hash_table.cpp:655-695) for records that arrived from other shards. */
 int kc_insert_records(kc_ctx *ctx, const uint64_t *d_records, uint64_t n);

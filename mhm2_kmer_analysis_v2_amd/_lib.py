@@ -69,6 +69,7 @@ SYMBOLS = {
     "kc_submit_seq_block": (C.c_int, [C.c_void_p, C.c_void_p, C.c_uint64, C.c_int]),
     "kc_extract_partition": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_uint64, C.c_int, C.c_void_p,
                                        C.c_uint64, C.c_void_p]),
+    "kc_extract_partition_seq_block": (C.c_int, [C.c_void_p, C.c_void_p, C.c_uint64, C.c_int, C.c_void_p, C.c_uint64, C.c_void_p]),
     "kc_insert_records": (C.c_int, [C.c_void_p, C.c_void_p, C.c_uint64]),
     "kc_flush": (C.c_int, [C.c_void_p]),
     "kc_finalize": (C.c_int, [C.c_void_p, C.POINTER(kc_result)]),

@@ -828,6 +828,29 @@ extern "C" int kc_extract_partition(kc_ctx *c, const uint8_t *bases, const uint8
   return KC_OK;
 }
 
+extern "C" int kc_extract_partition_seq_block(kc_ctx *c, const char *seqs, uint64_t len, int on_device, uint64_t *d_records,
+                                              uint64_t seg_capacity, uint64_t *h_counts) {
+  if (!c || !h_counts || (len && (!seqs || !d_records))) return KC_ERR_INVALID_ARG;
+  HIPCHK(hipSetDevice(c->cfg.device));
+  HIPCHK(hipMemsetAsync(c->d_ctrs + CTR_OVERFLOW, 0, (1 + 64) * 8, c->stream));
+  const uint8_t *d = (const uint8_t *)seqs;
+  if (len && !on_device) {
+    int rc = ensure_stage(c, (size_t)len, 0, false);
+    if (rc) return rc;
+    HIPCHK(hipStreamSynchronize(c->stream));
+    HIPCHK(hipMemcpyAsync(c->d_stage_bases, seqs, len, hipMemcpyHostToDevice, c->stream));
+    d = c->d_stage_bases;
+  }
+  int rc = run_extract_device(c, d, nullptr, nullptr, 0, len, MODE_BIN, FMT_SEQBLOCK, d_records, seg_capacity);
+  if (rc) return rc;
+  rc = sync_ctrs(c);
+  if (rc) return rc;
+  for (int t = 0; t < c->cfg.rank_n; t++) h_counts[t] = c->h_ctrs[CTR_BIN0 + t];
+  if (c->h_ctrs[CTR_BAD_BASE]) return KC_ERR_BAD_BASE;
+  if (c->h_ctrs[CTR_OVERFLOW]) return KC_ERR_CAPACITY;
+  return KC_OK;
+}
+
 template <int NL>
 static void launch_insert_records(kc_ctx *c, const uint64_t *recs, uint64_t n, uint32_t count_inserted) {
   unsigned nblk = (unsigned)std::min<uint64_t>((n + TPB - 1) / TPB, 256 * 32);

@@ -1,0 +1,83 @@
+// Exercises kcount_driver.hpp the way src/kcount/kcount_gpu.cpp drives the reference's device drivers:
+// sender bins a '_'-joined block by target, receivers take records (or supermers), done_all_inserts,
+// iterate.  Prints "KMER count L R" lines (kmer_dht.cpp:284 format), sorted, for the Python test to compare.
+#include <algorithm>
+#include <iostream>
+#include <string>
+#include <vector>
+
+#include "../../mhm2_kmer_analysis_v2_amd/csrc/kcount_driver.hpp"
+
+using namespace kcount_mi355;
+
+template <int MAX_K>
+static std::string kmer_str(const KmerArray<MAX_K> &k, int len) {
+  std::string s;
+  for (int i = 0; i < len; i++) s.push_back("ACGT"[(k.longs[i / 32] >> (2 * (31 - (i % 32)))) & 3]);
+  return s;
+}
+
+int main(int argc, char **argv) {
+  const int k = argc > 1 ? atoi(argv[1]) : 21;
+  const std::string mode = argc > 2 ? argv[2] : "records";
+  std::string block, line;
+  while (std::getline(std::cin, line)) block += line + "_";  // one case-masked read per line
+  const int R = 2;
+  std::vector<std::string> out;
+  std::string msgs, warnings;
+  double t = 0;
+  HashTableDriver<32> *ht[R];
+  for (int r = 0; r < R; r++) {
+    ht[r] = new HashTableDriver<32>();
+    ht[r]->init(r, R, k, 100000, 0, 10000, 0, msgs, warnings, false);
+  }
+  if (mode == "records") {
+    ParseAndPackDriver pnp(0, R, 33, k, kc_num_longs(k), 15, t);
+    unsigned nvalid = 0;
+    if (!pnp.process_seq_block(block, nvalid)) return 2;
+    for (int r = 0; r < R; r++)
+      ht[r]->insert_records(pnp.records() + (size_t)r * pnp.segment_capacity() * kc_num_longs(k), pnp.counts()[r]);
+  } else {
+    // supermer path: whole reads as ASCII supermers to rank 0 only works for R == 1 semantics, so route by
+    // giving every read to both and letting each keep what it owns is not possible here: use one shard
+    delete ht[1];
+    ht[1] = nullptr;
+    delete ht[0];
+    ht[0] = new HashTableDriver<32>();
+    ht[0]->init(0, 1, k, 100000, 0, 10000, 0, msgs, warnings, false);
+    size_t p = 0;
+    while (p < block.size()) {
+      size_t e = block.find('_', p);
+      std::string read = block.substr(p, e - p);
+      if (mode == "ascii") {
+        ht[0]->insert_supermer_ascii(read);
+      } else {  // 4-bit packed as parse_and_pack.cpp:196-237 packs it
+        std::string packed((read.size() + 1) / 2, '\0');
+        for (size_t i = 0; i < read.size(); i++) {
+          const char *codes = "_acgtACGTN";
+          unsigned v = read[i] == 'n' ? 9u : (unsigned)(std::string(codes).find(read[i]));  // N and n share code 9
+          packed[i / 2] |= (char)(i % 2 ? v : v << 4);
+        }
+        ht[0]->insert_supermer(packed, 1);
+      }
+      p = e + 1;
+    }
+  }
+  for (int r = 0; r < R; r++) {
+    if (!ht[r]) continue;
+    ht[r]->flush_inserts();
+    uint64_t dropped, unique, purged;
+    ht[r]->done_all_inserts(dropped, unique, purged);
+    if (dropped) return 3;
+    ht[r]->begin_iterate();
+    while (true) {
+      auto [key, val] = ht[r]->get_next_entry();
+      if (!key) break;
+      out.push_back(kmer_str<32>(*key, k) + " " + std::to_string(val->count) + " " + (char)val->left + " " + (char)val->right);
+    }
+    delete ht[r];
+  }
+  std::sort(out.begin(), out.end());
+  for (auto &l : out) std::cout << l << "\n";
+  return 0;
+}

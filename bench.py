@@ -35,6 +35,7 @@ def parse_args():
     ap.add_argument("--cpu-sample-reads", type=int, default=1_000_000, help="reads timed through the CPU oracle (0 = skip)")
     ap.add_argument("--check", action="store_true", help="size-independent result checks after the timed region")
     ap.add_argument("--table-path", action="store_true", help="A/B: force the global-table insert path instead of the bucketed one")
+    ap.add_argument("--tune", default="", help="A/B: bucketed-path geometry overrides, e.g. slots=2048,p1=1024,p2=1024")
     return ap.parse_args()
 
 
@@ -106,7 +107,7 @@ def main():
     # distinct k-mers: genomes (shared by all ranks) + ~k per substitution error
     genome_kmers = 64 * 4_000_000
     est_unique = int((genome_kmers + world * nreads * L * params.sub_error_rate * k * 1.05) / world) + (1 << 20)
-    ap_tuning = dict(mode=1) if a.table_path else None
+    ap_tuning = dict(mode=1) if a.table_path else ({k: int(v) for k, v in (kv.split("=") for kv in a.tune.split(","))} if a.tune else None)
     kc = pkg.KmerCounter(k, device=local_rank, rank_me=rank, rank_n=world, max_elems=est_unique, time_kernels=True,
                          max_kmers_buffered=int(nreads * (L - k - 1) * 1.02) + (1 << 20), tuning=ap_tuning)
     kc.set_stream(torch.cuda.current_stream().cuda_stream)

@@ -87,7 +87,8 @@ SYMBOLS = {
 
 
 def lib_path():
-    return os.path.join(_HERE, "csrc", "libkcount_mi355.so")
+    # KC_LIB: an alternative build of the same library (tuning experiments only)
+    return os.environ.get("KC_LIB") or os.path.join(_HERE, "csrc", "libkcount_mi355.so")
 
 
 def lib():

@@ -437,7 +437,8 @@ static int bk_init(kc_ctx *c) {
   const double est = c->cfg.max_elems ? (double)c->cfg.max_elems : 0.35 * (double)bcap;  // 1/depth(4) + error share, kmer_dht.cpp:126-131
   const uint32_t smax = count_smax(c->nl);
   g.S = t.slots ? std::min(std::max(t.slots, 16u), smax) : smax;
-  const uint64_t regions_needed = (uint64_t)(est / (0.7 * g.S)) + 1;  // LDS tables run at ~0.7 load
+  while (g.S & (g.S - 1)) g.S &= g.S - 1;  // power of two (round down)
+  const uint64_t regions_needed = (uint64_t)(est / (0.55 * g.S)) + 1;  // LDS tables are meant to run below ~0.55 load
   const uint32_t bits = std::min<uint32_t>(ilog2(regions_needed), 20);
   g.log2P1 = t.p1 ? ilog2(t.p1) : bits / 2;  // level 1 holds fewer records per round than level 2: give it the smaller fan-out
   g.log2P2 = t.p2 ? ilog2(t.p2) : (bits + 1) / 2;
@@ -1033,11 +1034,15 @@ static int bk_build_regions(kc_ctx *c) {
 template <int NL, bool DUMP>
 static int bk_count_t(kc_ctx *c, const OutBufs &ob) {
   auto kern = kc_count_kernel<NL, DUMP>;
-  int rc = set_dyn_lds(kern, sizeof(CountLDS<NL>));
+  const size_t lds = CountLDS<NL>::bytes(c->gm.S);
+  int rc = set_dyn_lds(kern, lds);
   if (rc) return rc;
   const uint64_t R = (uint64_t)c->gm.P1 * c->gm.P2;
+  // as many workgroups per CU as the LDS admits (at most 2: 1024 threads each), so that one region's barriers
+  // and scans overlap another's inserts
+  const unsigned per_cu = lds * 2 <= 160 * 1024 ? 2u : 1u;
   KernelTimer kt(c, KT_COUNT_REGIONS);
-  hipLaunchKernelGGL(kern, dim3((unsigned)std::min<uint64_t>(R, (uint64_t)c->num_cus)), dim3(WGB), sizeof(CountLDS<NL>), c->stream, c->gm, c->bb,
+  hipLaunchKernelGGL(kern, dim3((unsigned)std::min<uint64_t>(R, (uint64_t)c->num_cus * per_cu)), dim3(WGB), lds, c->stream, c->gm, c->bb,
                      ob, c->cfg.dmin_thres, c->d_ctrs, c->d_cb, (uint32_t)(getenv("KC_DEBUG_COUNT") ? atoi(getenv("KC_DEBUG_COUNT")) : 0));
   return KC_OK;
 }
@@ -1131,6 +1136,12 @@ static int bk_finalize(kc_ctx *c) {
     if (rc) return rc;
     rc = sync_ctrs(c);
     if (rc) return rc;
+    if (getenv("KC_DEBUG_COUNT") && (atoi(getenv("KC_DEBUG_COUNT")) & 512)) {  // diagnostic stamps of kc_count_kernel
+      (void)sync_cb(c);
+      fprintf(stderr, "count kernel cycles (workgroup wave 0, summed over %d workgroups): zero %llu insert %llu satscan %llu vote %llu write %llu\n",
+              c->num_cus, (unsigned long long)c->h_cb[8], (unsigned long long)c->h_cb[9], (unsigned long long)c->h_cb[10],
+              (unsigned long long)c->h_cb[11], (unsigned long long)c->h_cb[12]);
+    }
     if (c->h_ctrs[CTR_OUT] <= c->out_cap) break;
     cap = c->h_ctrs[CTR_OUT];  // the pass only counted past the end: run it again with exactly enough room
   }

@@ -75,8 +75,8 @@ enum {  // counters of this path, one u64 each
 
 __device__ __forceinline__ uint32_t hash_b1(uint64_t h, const Geom &g) { return (uint32_t)h & (g.P1 - 1); }
 __device__ __forceinline__ uint32_t hash_b2(uint64_t h, const Geom &g) { return (uint32_t)(h >> g.log2P1) & (g.P2 - 1); }
-__device__ __forceinline__ uint32_t hash_slot(uint64_t h, uint32_t S) {
-  return (uint32_t)(((uint64_t)(uint32_t)(h >> 21) * (uint64_t)S) >> 32);
+__device__ __forceinline__ uint32_t hash_slot(uint64_t h, uint32_t S) {  // S is a power of two
+  return (uint32_t)(h >> 21) & (S - 1u);
 }
 
 template <int NL>
@@ -519,16 +519,46 @@ __global__ void kc_ovf1_to_regions_kernel(Geom gm, BucketBufs bb, uint64_t n, ui
 constexpr uint32_t CHAIN_LDS = 512;  // longest region chain (L2MAX) the count kernel can stage
 
 // LDS image of one region, structure-of-arrays so that neighbouring slots sit in neighbouring banks.
+// The table size is a power of two (cheap wrap, low load: the probe loop runs in lock step, so a wave pays for
+// its longest probe).  The eight extension counters are packed two per word (16 bits each): a half can only
+// overflow when the k-mer itself was seen more than 65535 times, and then the whole region is handed to the
+// global table (flag 2), whose counters are 32 bits wide.
 template <int NL>
-struct CountLDS {
-  static constexpr uint32_t SMAX = (147456 - 64 - 4 * CHAIN_LDS) / (8 * NL + 36);
-  uint64_t keys[SMAX * NL];  // word w of slot s at keys[w*SMAX + s]; the LAST word is the claim word
-  uint32_t cnt[SMAX];
-  uint32_t ext[8 * SMAX];    // ext[e*SMAX + s]
+struct CountLDS {  // header at the start of the dynamic LDS; the arrays follow, strided by the region's S
+  static constexpr uint32_t SMAX = NL <= 2 ? 4096 : 2048;
   uint32_t chain[CHAIN_LDS];  // the region's chunk ids
   uint32_t nout, nent, fail, gbase_lo, gbase_hi;
   unsigned long long sum;
+  static constexpr size_t header_bytes() { return (sizeof(CountLDS<NL>) + 15) & ~size_t(15); }
+  static constexpr size_t bytes(uint32_t S) { return header_bytes() + (size_t)S * (8 * NL + 20); }
 };
+
+// the arrays of one region table: word w of slot s at keys[w*S + s] (the LAST word is the claim word);
+// ext[q*S + s]: q = 0 left A|C<<16, 1 left G|T<<16, 2 right A|C<<16, 3 right G|T<<16
+struct CountTab {
+  uint64_t *keys;
+  uint32_t *cnt;
+  uint32_t *ext;
+  uint32_t S;
+};
+
+template <int NL>
+__device__ __forceinline__ CountTab count_tab(uint8_t *smem, uint32_t S) {
+  CountTab t;
+  t.keys = reinterpret_cast<uint64_t *>(smem + CountLDS<NL>::header_bytes());
+  t.cnt = reinterpret_cast<uint32_t *>(t.keys + (size_t)NL * S);
+  t.ext = t.cnt + S;
+  t.S = S;
+  return t;
+}
+
+// bump the counter of extension code e (0-3) on side (0 left, 1 right)
+__device__ __forceinline__ void ext_bump(uint32_t *ext, uint32_t SM, uint32_t s, uint32_t side, uint32_t e) {
+  atomicAdd(&ext[(2 * side + (e >> 1)) * SM + s], 1u << (16 * (e & 1u)));
+}
+__device__ __forceinline__ uint32_t ext_get(const uint32_t *ext, uint32_t SM, uint32_t s, uint32_t side, uint32_t e) {
+  return (ext[(2 * side + (e >> 1)) * SM + s] >> (16 * (e & 1u))) & 0xFFFFu;
+}
 
 struct OutBufs {
   uint64_t *keys;
@@ -540,15 +570,15 @@ struct OutBufs {
 };
 
 template <int NL>
-__device__ __forceinline__ void lds_insert(CountLDS<NL> &T, uint32_t S, const uint64_t (&rec)[NL], uint32_t dbg = 0) {
-  constexpr uint32_t SM = CountLDS<NL>::SMAX;
+__device__ __forceinline__ void lds_insert(CountLDS<NL> &T, const CountTab &tb, const uint64_t (&rec)[NL]) {
+  const uint32_t SM = tb.S, S = tb.S;
   uint64_t key[NL];
 #pragma unroll
   for (int j = 0; j < NL; j++) key[j] = rec[j];
   const uint32_t le = (uint32_t)(rec[NL - 1] & 7u), re = (uint32_t)((rec[NL - 1] >> 3) & 7u);
   key[NL - 1] &= ~KC_EXT_MASK;
   uint32_t s = hash_slot(kc_hash<NL>(key), S);
-  unsigned long long *claim = (unsigned long long *)&T.keys[(NL - 1) * SM];
+  unsigned long long *claim = (unsigned long long *)&tb.keys[(NL - 1) * SM];
   uint32_t probes = 0;
   for (;;) {
     unsigned long long cur = __hip_atomic_load(&claim[s], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
@@ -557,11 +587,11 @@ __device__ __forceinline__ void lds_insert(CountLDS<NL> &T, uint32_t S, const ui
       if (cur == KEY_EMPTY) {
         if (NL > 1) {
 #pragma unroll
-          for (int j = 0; j < NL - 1; j++) T.keys[j * SM + s] = key[j];
+          for (int j = 0; j < NL - 1; j++) tb.keys[j * SM + s] = key[j];
           __threadfence_block();
           atomicExch(&claim[s], (unsigned long long)key[NL - 1]);
         }
-        if (!(dbg & 8u)) atomicAdd(&T.nent, 1u);
+        atomicAdd(&T.nent, 1u);
         break;
       }
     }
@@ -570,70 +600,49 @@ __device__ __forceinline__ void lds_insert(CountLDS<NL> &T, uint32_t S, const ui
       bool same = true;
       if (NL > 1) {
 #pragma unroll
-        for (int j = 0; j < NL - 1; j++) same &= (T.keys[j * SM + s] == key[j]);
+        for (int j = 0; j < NL - 1; j++) same &= (tb.keys[j * SM + s] == key[j]);
       }
       if (same) break;
     }
-    s = (s + 1 == S) ? 0 : s + 1;
+    s = (s + 1) & (S - 1u);
     if (++probes >= S) {  // every slot holds some other k-mer
       T.fail = 1;
       return;
     }
   }
-  if (dbg & 16u) return;
-  atomicAdd(&T.cnt[s], 1u);
-  if (dbg & 32u) return;
-  if (le < 4u) atomicAdd(&T.ext[le * SM + s], 1u);
-  if (re < 4u) atomicAdd(&T.ext[(4 + re) * SM + s], 1u);
+  atomicAdd(&tb.cnt[s], 1u);
+  if (le < 4u) ext_bump(tb.ext, SM, s, 0, le);
+  if (re < 4u) ext_bump(tb.ext, SM, s, 1, re);
 }
 
-// One-word keys: B records of a lane probe together.  Every probe is a single LDS compare-and-swap
-// (EMPTY -> key) whose return value tells "claimed", "already there" or "someone else": the B CAS of a
-// trip are issued back to back and waited for once, so the LDS round trips of the lock-stepped lanes
-// overlap instead of adding up (a wave leaves the loop only when its slowest lane has found its slot).
-template <int B>
-__device__ __forceinline__ void lds_insert_multi(CountLDS<1> &T, uint32_t S, const uint64_t (&rec)[B][1], const bool (&valid)[B]) {
-  constexpr uint32_t SM = CountLDS<1>::SMAX;
-  unsigned long long *claim = (unsigned long long *)&T.keys[0];
-  uint64_t key[B];
-  uint32_t s[B], probes = 0, nnew = 0;
-  bool act[B];
-#pragma unroll
-  for (int j = 0; j < B; j++) {
-    key[j] = rec[j][0] & ~KC_EXT_MASK;
-    uint64_t kk[1] = {key[j]};
-    s[j] = hash_slot(kc_hash<1>(kk), S);
-    act[j] = valid[j];
-  }
-  for (;;) {
-    bool any = false;
-#pragma unroll
-    for (int j = 0; j < B; j++) any |= act[j];
-    if (!any) break;
-    unsigned long long old[B];
-#pragma unroll
-    for (int j = 0; j < B; j++)
-      if (act[j]) old[j] = atomicCAS(&claim[s[j]], (unsigned long long)KEY_EMPTY, (unsigned long long)key[j]);
-#pragma unroll
-    for (int j = 0; j < B; j++) {
-      if (!act[j]) continue;
-      if (old[j] == KEY_EMPTY || old[j] == key[j]) {
-        nnew += (old[j] == KEY_EMPTY);
-        act[j] = false;
-        const uint32_t le = (uint32_t)(rec[j][0] & 7u), re = (uint32_t)((rec[j][0] >> 3) & 7u);
-        atomicAdd(&T.cnt[s[j]], 1u);
-        if (le < 4u) atomicAdd(&T.ext[le * SM + s[j]], 1u);
-        if (re < 4u) atomicAdd(&T.ext[(4 + re) * SM + s[j]], 1u);
-      } else {
-        s[j] = (s[j] + 1 == S) ? 0 : s[j] + 1;
-      }
-    }
-    if (++probes > S) {  // every slot holds some other k-mer
-      T.fail = 1;
+// One-word keys: the probe written for a low instruction count.  The region kernels are bound by instruction
+// issue (PMC: as many scalar as vector instructions, almost no idle LDS or HBM), and the lanes of a wave probe in
+// lock step, so every trip of this loop is paid by all 64 lanes.  Predicates are kept as 0/1 integers in vector
+// registers (compares produce lane masks in scalar registers, and combining those is scalar work); each trip is one
+// LDS compare-and-swap EMPTY -> key whose return value says "claimed" (EMPTY), "already there" (key) or "someone
+// else"; lanes that are done keep issuing a CAS that can never match (expected value KEY_BUSY never occurs in a
+// one-word table), i.e. a plain read.  Returns the slot; counts nothing (the caller bumps the counters, and the
+// number of entries is counted when the table is scanned).
+__device__ __forceinline__ uint32_t lds_probe1(unsigned long long *claim, uint32_t Sm1, uint64_t key, uint32_t slot, uint32_t valid,
+                                               uint32_t &failed) {
+  uint32_t act = valid;
+  const uint32_t klo = (uint32_t)key, khi = (uint32_t)(key >> 32);
+  uint32_t trips = 0;
+  do {
+    unsigned long long old = key;  // a lane that is done looks like a hit below
+    if (act) old = atomicCAS(&claim[slot], (unsigned long long)KEY_EMPTY, (unsigned long long)key);  // only live lanes touch the LDS
+    const uint32_t olo = (uint32_t)old, ohi = (uint32_t)(old >> 32);
+    const uint32_t differs = (olo ^ klo) | (ohi ^ khi);  // 0 iff the slot holds this key
+    const uint32_t notempty = ~(olo & ohi);              // 0 iff the slot was EMPTY (and is now ours)
+    const uint32_t miss = min(differs, notempty) ? act : 0u;
+    act = miss;
+    slot = (slot + miss) & Sm1;
+    if (++trips > Sm1 + 1) {  // every slot holds some other k-mer (wave-uniform exit)
+      failed |= act;
       break;
     }
-  }
-  if (nnew) atomicAdd(&T.nent, nnew);
+  } while (__any(act));
+  return slot;
 }
 
 // DUMP = false: S7 vote + S8 purge, survivors to the result arrays.  DUMP = true: every entry with its raw
@@ -643,20 +652,30 @@ __global__ __launch_bounds__(WGB) void kc_count_kernel(Geom gm, BucketBufs bb, O
                                                        uint64_t *cb, uint32_t dbg) {
   extern __shared__ __align__(16) uint8_t smem[];
   CountLDS<NL> &T = *reinterpret_cast<CountLDS<NL> *>(smem);
-  constexpr uint32_t SM = CountLDS<NL>::SMAX;
   const int tid = threadIdx.x;
-  const uint32_t S = gm.S;
+  const uint32_t S = gm.S, SM = gm.S;
+  const CountTab tb = count_tab<NL>(smem, S);
   const size_t R = (size_t)gm.P1 * gm.P2;
+  // diagnostic only (dbg & 512): wave 0 accumulates the cycles between the phase boundaries of every region into cb[8..]
+  unsigned long long tacc[6] = {0, 0, 0, 0, 0, 0}, tprev = 0;
+  const bool stamp = (dbg & 512u) && tid == 0;
+#define KC_STAMP(k)                                        \
+  if (stamp) {                                             \
+    const unsigned long long tn = __builtin_amdgcn_s_memtime(); \
+    tacc[k] += tn - tprev;                                 \
+    tprev = tn;                                            \
+  }
   for (size_t r = blockIdx.x; r < R; r += gridDim.x) {
     const uint32_t n = bb.cnt2[r];
     if (n == 0 || bb.flag[r]) continue;  // uniform across the workgroup
+    if (stamp) tprev = __builtin_amdgcn_s_memtime();
     if (!(dbg & 4u))
     for (uint32_t s = tid; s < S; s += WGB) {
 #pragma unroll
-      for (int w = 0; w < NL; w++) T.keys[w * SM + s] = KEY_EMPTY;
-      T.cnt[s] = 0;
+      for (int w = 0; w < NL; w++) tb.keys[w * SM + s] = KEY_EMPTY;
+      tb.cnt[s] = 0;
 #pragma unroll
-      for (int e = 0; e < 8; e++) T.ext[e * SM + s] = 0;
+      for (int e = 0; e < 4; e++) tb.ext[e * SM + s] = 0;
     }
     if (tid == 0) {
       T.nout = 0;
@@ -669,45 +688,75 @@ __global__ __launch_bounds__(WGB) void kc_count_kernel(Geom gm, BucketBufs bb, O
       if ((uint32_t)tid < nch) T.chain[tid] = bb.chain2[r * gm.L2MAX + tid];
     }
     __syncthreads();
+    KC_STAMP(0)  // zero + chain
     // several independent loads in flight per thread before the dependent LDS work starts
-    constexpr int BATCH = NL == 1 ? 8 : NL == 2 ? 4 : 2;
+#ifndef KC_BATCH
+#define KC_BATCH 8
+#endif
+    constexpr int BATCH = NL == 1 ? KC_BATCH : NL == 2 ? 4 : 2;
     const uint32_t CHm = (1u << gm.log2CH2) - 1u;
     for (uint32_t i0 = 0; i0 < n; i0 += WGB * BATCH) {
       uint64_t rec[BATCH][NL];
+      // no branches around the loads (an out-of-range lane re-reads record 0): the compiler can then issue
+      // all of them before the first wait instead of fencing each one off in its own basic block
+      const uint64_t *src[BATCH];
 #pragma unroll
       for (int j = 0; j < BATCH; j++) {
-        const uint32_t i = i0 + (uint32_t)j * WGB + tid;
-        if (i < n) {
-          const uint64_t *src = bb.rec2 + (((size_t)T.chain[i >> gm.log2CH2] << gm.log2CH2) + (i & CHm)) * NL;
-#pragma unroll
-          for (int w = 0; w < NL; w++) rec[j][w] = src[w];
-        }
+        uint32_t i = i0 + (uint32_t)j * WGB + tid;
+        i = i < n ? i : 0u;
+        src[j] = bb.rec2 + (((size_t)T.chain[i >> gm.log2CH2] << gm.log2CH2) + (i & CHm)) * NL;
       }
+#pragma unroll
+      for (int j = 0; j < BATCH; j++)
+#pragma unroll
+        for (int w = 0; w < NL; w++) rec[j][w] = src[j][w];
       if constexpr (NL == 1) {
-        bool valid[BATCH];
+        if (!(dbg & 1u)) {
+          uint32_t failed = 0;
 #pragma unroll
-        for (int j = 0; j < BATCH; j++) valid[j] = (i0 + (uint32_t)j * WGB + tid) < n;
-        if (dbg & 1u) {
-#pragma unroll
-          for (int j = 0; j < BATCH; j++)
-            if (valid[j] && rec[j][0] == 0x123456789ULL) T.fail = 1;  // keep the loads alive
-        } else {
-          lds_insert_multi<BATCH>(T, S, rec, valid);
+          for (int j = 0; j < BATCH; j++) {
+            const uint32_t v = (i0 + (uint32_t)j * WGB + tid) < n ? 1u : 0u;
+            const uint64_t r0 = rec[j][0], key = r0 & ~KC_EXT_MASK;
+            uint64_t kk[1] = {key};
+            const uint32_t s = lds_probe1((unsigned long long *)tb.keys, S - 1u, key, hash_slot(kc_hash<1>(kk), S), v, failed);
+            // S5/S6: the k-mer itself, and each extension that is an ACGT base (codes 0-3; 4 = none adds 0)
+            const uint32_t le = (uint32_t)r0 & 7u, re = ((uint32_t)r0 >> 3) & 7u;
+            atomicAdd(&tb.cnt[s], v);
+            atomicAdd(&tb.ext[((le >> 1) & 1u) * SM + s], (v << ((le & 1u) << 4)) & (((le >> 2) & 1u) - 1u));
+            atomicAdd(&tb.ext[(2u + ((re >> 1) & 1u)) * SM + s], (v << ((re & 1u) << 4)) & (((re >> 2) & 1u) - 1u));
+          }
+          if (failed) T.fail = 1;
         }
       } else {
 #pragma unroll
         for (int j = 0; j < BATCH; j++) {
           const uint32_t i = i0 + (uint32_t)j * WGB + tid;
-          if (i < n) lds_insert<NL>(T, S, rec[j], dbg);
+          if (i < n) lds_insert<NL>(T, tb, rec[j]);
         }
       }
     }
     __syncthreads();
-    if (T.fail) {  // more distinct k-mers than slots: the whole region goes to the global table instead
+    KC_STAMP(1)  // loads + inserts + barrier
+    // a k-mer seen more than 65535 times may have overflowed a packed 16-bit extension counter
+    {
+      uint32_t ne = 0;
+      for (uint32_t s = tid; s < S; s += WGB) {
+        const uint32_t c = tb.cnt[s];
+        ne += c != 0;
+        if (c > KC_COUNT_MAX) T.fail = 1;
+      }
+      if (NL == 1) {  // one-word inserts do not count new entries one by one
+        for (int o = 32; o > 0; o >>= 1) ne += __shfl_down(ne, o);
+        if (lane_id() == 0 && ne) atomicAdd(&T.nent, ne);
+      }
+    }
+    __syncthreads();
+    if (T.fail) {  // more distinct k-mers than slots, or a saturated k-mer: the whole region goes to the global table instead
       if (tid == 0) bb.flag[r] = 2;
       __syncthreads();
       continue;
     }
+    KC_STAMP(2)  // saturation scan
     // S7 vote + S8 purge; survivors get a rank
     if (dbg & 2u) {
       __syncthreads();
@@ -715,16 +764,16 @@ __global__ __launch_bounds__(WGB) void kc_count_kernel(Geom gm, BucketBufs bb, O
     }
     for (uint32_t s = tid; s < S; s += WGB) {
       uint32_t packed = ~0u;
-      if (T.keys[(NL - 1) * SM + s] != KEY_EMPTY) {
-        const uint32_t count = min(T.cnt[s], KC_COUNT_MAX);
+      if (tb.keys[(NL - 1) * SM + s] != KEY_EMPTY) {
+        const uint32_t count = tb.cnt[s];  // <= 65535 here: regions with a larger count were flagged above
         if (DUMP) {
           packed = count | (atomicAdd(&T.nout, 1u) << 20);
         } else if (count >= 2) {
           uint32_t lc[4], rc[4];
 #pragma unroll
           for (int e = 0; e < 4; e++) {
-            lc[e] = min(T.ext[e * SM + s], KC_COUNT_MAX);
-            rc[e] = min(T.ext[(4 + e) * SM + s], KC_COUNT_MAX);
+            lc[e] = ext_get(tb.ext, SM, s, 0, e);
+            rc[e] = ext_get(tb.ext, SM, s, 1, e);
           }
           const uint32_t l = vote_ext(lc, count, dmin_thres), rr = vote_ext(rc, count, dmin_thres);
           if (l < 4u && rr < 4u) {
@@ -734,7 +783,7 @@ __global__ __launch_bounds__(WGB) void kc_count_kernel(Geom gm, BucketBufs bb, O
           }
         }
       }
-      T.cnt[s] = packed;
+      tb.cnt[s] = packed;
     }
     __syncthreads();
     if (tid == 0) {
@@ -748,18 +797,19 @@ __global__ __launch_bounds__(WGB) void kc_count_kernel(Geom gm, BucketBufs bb, O
       }
     }
     __syncthreads();
+    KC_STAMP(3)  // vote + reserve
     const uint64_t gbase = ((uint64_t)T.gbase_hi << 32) | T.gbase_lo;
     for (uint32_t s = tid; s < S; s += WGB) {
-      const uint32_t p = T.cnt[s];
+      const uint32_t p = tb.cnt[s];
       if (p == ~0u) continue;
       const uint64_t o = gbase + (p >> 20);
       if (o < out.cap) {  // beyond the arrays: the host sees the cursor past cap and re-runs with more room
 #pragma unroll
-        for (int w = 0; w < NL; w++) out.keys[o * NL + w] = T.keys[w * SM + s];
+        for (int w = 0; w < NL; w++) out.keys[o * NL + w] = tb.keys[w * SM + s];
         out.counts[o] = (uint16_t)(p & 0xFFFFu);
         if (DUMP) {
 #pragma unroll
-          for (int e = 0; e < 8; e++) out.exts[o * 8 + e] = (uint16_t)min(T.ext[e * SM + s], KC_COUNT_MAX);
+          for (int e = 0; e < 8; e++) out.exts[o * 8 + e] = (uint16_t)ext_get(tb.ext, SM, s, e >> 2, e & 3);
         } else {
           out.left[o] = (uint8_t)("ACGT"[(p >> 16) & 3u]);
           out.right[o] = (uint8_t)("ACGT"[(p >> 18) & 3u]);
@@ -767,7 +817,11 @@ __global__ __launch_bounds__(WGB) void kc_count_kernel(Geom gm, BucketBufs bb, O
       }
     }
     __syncthreads();
+    KC_STAMP(4)  // write out
   }
+  if (stamp)
+    for (int k = 0; k < 5; k++) atomicAdd((unsigned long long *)&cb[8 + k], tacc[k]);
+#undef KC_STAMP
 }
 
 // records of flagged regions go to the global table (kc_kernels.hpp): one workgroup per flagged region at a time

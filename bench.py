@@ -35,6 +35,7 @@ def parse_args():
     ap.add_argument("--cpu-sample-reads", type=int, default=1_000_000, help="reads timed through the CPU oracle (0 = skip)")
     ap.add_argument("--check", action="store_true", help="size-independent result checks after the timed region")
     ap.add_argument("--table-path", action="store_true", help="A/B: force the global-table insert path instead of the bucketed one")
+    ap.add_argument("--force-sharded", action="store_true", help="run the N>1 code path (bin by owner, exchange, insert records) even at N=1")
     ap.add_argument("--tune", default="", help="A/B: bucketed-path geometry overrides, e.g. slots=2048,p1=1024,p2=1024")
     return ap.parse_args()
 
@@ -91,7 +92,11 @@ def main():
         raise SystemExit("bench.py needs a GPU: the HIP path is the only path")
     torch.cuda.set_device(local_rank)
     dev = torch.device("cuda", local_rank)
-    if world > 1:
+    sharded_path = world > 1 or a.force_sharded
+    if sharded_path:
+        if world == 1:
+            os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+            os.environ.setdefault("MASTER_PORT", "29533")
         dist.init_process_group("nccl", rank=rank, world_size=world, device_id=dev)
 
     k, L = a.k, 150
@@ -115,7 +120,7 @@ def main():
     torch.cuda.synchronize()
 
     sharded = None
-    if world > 1:
+    if sharded_path:
         blk = min(a.block_reads, nreads)
         seg = int(blk * (L - k - 1) / world * 1.25) + 4096
 
@@ -129,16 +134,17 @@ def main():
 
     def step():
         kc.reset()
-        if world == 1:
+        if not sharded_path:
             kc.submit_reads(d_bases, d_quals, d_offs, nreads=nreads)
         else:
             for r0 in range(0, nreads, a.block_reads):
                 sharded.add_block((r0, min(nreads, r0 + a.block_reads)))
+            sharded.finish()
         return kc.finalize()
 
     def fence():
         torch.cuda.synchronize()
-        if world > 1:
+        if sharded_path:
             dist.barrier()
         torch.cuda.synchronize()
 
@@ -223,7 +229,7 @@ def main():
         out["cpu_baseline"] = None
     if rank == 0:
         print(json.dumps(out), flush=True)
-    if world > 1:
+    if sharded_path:
         dist.barrier()
         dist.destroy_process_group()
 

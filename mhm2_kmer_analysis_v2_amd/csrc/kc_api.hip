@@ -36,7 +36,7 @@ static int hip_fail(hipError_t e, const char *what, int line) {
 
 enum { KT_EXTRACT_INSERT = 0, KT_EXTRACT_BIN, KT_INSERT_RECORDS, KT_FINALIZE, KT_TILE_FIRST, KT_REHASH, KT_L1_READS, KT_L1_RECORDS,
        KT_L2_SPLIT, KT_COUNT_REGIONS, KT_FALLBACK, KT_COUNT };
-static const char *const kt_names[KT_COUNT] = {"kc_extract_kernel<insert>", "kc_extract_kernel<bin>", "kc_insert_records_kernel",
+static const char *const kt_names[KT_COUNT] = {"kc_extract_kernel<insert>", "kc_bin_reads_kernel", "kc_insert_records_kernel",
                                                "kc_finalize_kernel", "kc_tile_first_kernel", "kc_rehash_kernel",
                                                "kc_l1_reads_kernel", "kc_l1_records_kernel", "kc_l2_split_kernel",
                                                "kc_count_kernel", "kc_flagged_to_table_kernel"};
@@ -538,6 +538,35 @@ static int launch_l1_reads(kc_ctx *c, const ExtractArgs &a, uint64_t ntiles, int
   }
 }
 
+template <int NL, int FMT>
+static int launch_bin_reads_t(kc_ctx *c, const ExtractArgs &a, uint64_t ntiles) {
+  auto kern = kc_bin_reads_kernel<NL, FMT>;
+  int rc = set_dyn_lds(kern, lds_l1_reads<NL>());
+  if (rc) return rc;
+  const uint64_t nsuper = (ntiles + QUARTERS - 1) / QUARTERS;
+  const unsigned grid = (unsigned)std::min<uint64_t>((uint64_t)c->num_cus, nsuper);
+  KernelTimer kt(c, KT_EXTRACT_BIN);
+  hipLaunchKernelGGL(kern, dim3(grid), dim3(WGB), lds_l1_reads<NL>(), c->stream, a, ntiles, c->d_ctrs);
+  return KC_OK;
+}
+
+static int launch_bin_reads(kc_ctx *c, const ExtractArgs &a, uint64_t ntiles, int fmt) {
+  if (fmt == FMT_READS) {
+    switch (c->nl) {
+      case 1: return launch_bin_reads_t<1, FMT_READS>(c, a, ntiles);
+      case 2: return launch_bin_reads_t<2, FMT_READS>(c, a, ntiles);
+      case 3: return launch_bin_reads_t<3, FMT_READS>(c, a, ntiles);
+      default: return launch_bin_reads_t<4, FMT_READS>(c, a, ntiles);
+    }
+  }
+  switch (c->nl) {
+    case 1: return launch_bin_reads_t<1, FMT_SEQBLOCK>(c, a, ntiles);
+    case 2: return launch_bin_reads_t<2, FMT_SEQBLOCK>(c, a, ntiles);
+    case 3: return launch_bin_reads_t<3, FMT_SEQBLOCK>(c, a, ntiles);
+    default: return launch_bin_reads_t<4, FMT_SEQBLOCK>(c, a, ntiles);
+  }
+}
+
 template <int NL>
 static int launch_l1_records_t(kc_ctx *c, const uint64_t *recs, uint64_t n) {
   auto kern = kc_l1_records_kernel<NL>;
@@ -664,7 +693,7 @@ static int run_extract_device(kc_ctx *c, const uint8_t *bases, const uint8_t *qu
   while (t0 < ntiles_total) {
     const bool bk = (mode == MODE_INSERT) && bk_active(c);
     uint64_t chunk_tiles;
-    if (bk) {
+    if (bk || mode == MODE_BIN) {
       chunk_tiles = (1ULL << 31) / TILE;
     } else {
       // a chunk may add at most one new entry per position: keep it within a quarter of the table
@@ -695,6 +724,9 @@ static int run_extract_device(kc_ctx *c, const uint8_t *bases, const uint8_t *qu
     if (bk) {
       int rc = launch_l1_reads(c, a, nt, fmt);
       if (rc) return rc;
+    } else if (mode == MODE_BIN) {
+      int rc = launch_bin_reads(c, a, nt, fmt);
+      if (rc) return rc;
     } else {
       launch_extract(c, a, (unsigned)nt, mode, fmt);
     }
@@ -705,10 +737,11 @@ static int run_extract_device(kc_ctx *c, const uint8_t *bases, const uint8_t *qu
   return KC_OK;
 }
 
-static int raw_kmer_stats(kc_ctx *c, const uint64_t *d_offsets, uint64_t nreads) {
+static int raw_kmer_stats(kc_ctx *c, const uint64_t *d_offsets, uint64_t nreads, int mode) {
   if (!nreads) return KC_OK;
   unsigned nblk = (unsigned)std::min<uint64_t>((nreads + 255) / 256, 4096);
-  hipLaunchKernelGGL(kc_read_stats_kernel, dim3(nblk), dim3(256), 0, c->stream, d_offsets, nreads, c->k, c->d_ctrs);
+  hipLaunchKernelGGL(kc_read_stats_kernel, dim3(nblk), dim3(256), 0, c->stream, d_offsets, nreads, c->k, c->d_ctrs,
+                     mode == MODE_INSERT ? 1u : 0u);
   c->num_gpu_calls++;
   HIPCHK(hipGetLastError());
   return KC_OK;
@@ -748,7 +781,7 @@ static int submit_reads_impl(kc_ctx *c, const uint8_t *bases, const uint8_t *qua
     HIPCHK(hipMemcpyAsync(&ends[1], offsets + nreads, 8, hipMemcpyDeviceToHost, c->stream));
     HIPCHK(hipStreamSynchronize(c->stream));
     if (ends[0] != 0) return KC_ERR_INVALID_ARG;  // offsets are relative to `bases`
-    int rc = raw_kmer_stats(c, offsets, nreads);
+    int rc = raw_kmer_stats(c, offsets, nreads, mode);
     if (rc) return rc;
     rc = run_extract_device(c, bases, quals, offsets, nreads, ends[1], mode, FMT_READS, d_records, seg_capacity);
     if (rc) return rc;
@@ -774,7 +807,7 @@ static int submit_reads_impl(kc_ctx *c, const uint8_t *bases, const uint8_t *qua
     HIPCHK(hipMemcpyAsync(c->d_stage_quals, quals + offsets[r0], nb, hipMemcpyHostToDevice, c->stream));
     HIPCHK(hipMemcpyAsync(c->d_stage_offsets, rel.data(), (nr + 1) * 8, hipMemcpyHostToDevice, c->stream));
     HIPCHK(hipStreamSynchronize(c->stream));  // rel is reused next trip
-    rc = raw_kmer_stats(c, c->d_stage_offsets, nr);
+    rc = raw_kmer_stats(c, c->d_stage_offsets, nr, mode);
     if (rc) return rc;
     rc = run_extract_device(c, c->d_stage_bases, c->d_stage_quals, c->d_stage_offsets, nr, nb, mode, FMT_READS, d_records,
                             seg_capacity);
@@ -805,7 +838,7 @@ extern "C" int kc_submit_seq_block(kc_ctx *c, const char *seqs, uint64_t len, in
     d = c->d_stage_bases;
   }
   unsigned nblk = (unsigned)std::min<uint64_t>((len + 255) / 256, 4096);
-  hipLaunchKernelGGL(kc_seqblock_stats_kernel, dim3(nblk), dim3(256), 0, c->stream, d, len, c->k, c->d_ctrs);
+  hipLaunchKernelGGL(kc_seqblock_stats_kernel, dim3(nblk), dim3(256), 0, c->stream, d, len, c->k, c->d_ctrs, 1u);
   c->num_gpu_calls++;
   int rc = run_extract_device(c, d, nullptr, nullptr, 0, len, MODE_INSERT, FMT_SEQBLOCK, nullptr, 0);
   if (rc) return rc;

@@ -323,6 +323,104 @@ __global__ __launch_bounds__(WGB) void kc_l1_reads_kernel(ExtractArgs a, Geom gm
   if (lane_id() == 0 && n_ins) atomicAdd((unsigned long long *)&ctrs[CTR_INSERTED], (unsigned long long)n_ins);
 }
 
+// ---- sender side of the shard exchange: bin a block's records by owner shard ------------------------------
+// Same tile extraction and LDS multisplit as level 1, with the owner shard as the bucket and the caller's
+// per-shard segments as destinations: one global cursor bump per shard and round (a handful of atomics per
+// 8 Ki records) instead of one per wave and shard.
+template <int NL, int R, class BucketFn>
+__device__ __forceinline__ void split_round_flat(SplitLDS &L, uint64_t *sorted, int buf, uint32_t P, const uint64_t (&rec)[R][NL],
+                                                 const uint32_t (&br)[R], uint64_t *records, uint64_t seg_cap, uint64_t *cursors,
+                                                 uint64_t *overflow_flag, BucketFn bucket_of) {
+  const int tid = threadIdx.x;
+  uint32_t *H = L.hist[buf];
+  const uint32_t v = ((uint32_t)tid < P) ? H[tid] : 0u;
+  const uint32_t excl = block_excl_scan(v, L.scan);
+  if ((uint32_t)tid < P) {
+    L.offs[tid] = excl;
+    uint64_t base = 0;
+    if (v) base = atomicAdd((unsigned long long *)&cursors[tid], (unsigned long long)v);
+    const uint64_t room = base < seg_cap ? seg_cap - base : 0;
+    L.dbase[tid] = (uint32_t)base;
+    L.c0[tid] = (uint32_t)(base >> 32);
+    H[tid] = (uint64_t)v <= room ? v : (uint32_t)room;
+    L.hist[buf ^ 1][tid] = 0;
+  }
+  lds_barrier();
+  const uint32_t total = L.scan.total;
+#pragma unroll
+  for (int j = 0; j < R; j++) {
+    if (br[j] != ~0u) {
+      const uint32_t b = br[j] & (PMAX - 1), rank = br[j] >> 10;
+      const uint32_t pos = L.offs[b] + rank;
+#pragma unroll
+      for (int w = 0; w < NL; w++) sorted[(size_t)pos * NL + w] = rec[j][w];
+    }
+  }
+  lds_barrier();
+  for (uint32_t i = tid; i < total; i += WGB) {
+    uint64_t r[NL];
+#pragma unroll
+    for (int w = 0; w < NL; w++) r[w] = sorted[(size_t)i * NL + w];
+    const uint32_t b = bucket_of(rec_hash<NL>(r));
+    const uint32_t j = i - L.offs[b];
+    if (j < H[b]) {
+      const uint64_t base = ((uint64_t)L.c0[b] << 32) | L.dbase[b];
+      uint64_t *d = records + ((uint64_t)b * seg_cap + base + j) * NL;
+#pragma unroll
+      for (int w = 0; w < NL; w++) d[w] = r[w];
+    } else {
+      *overflow_flag = 1;
+    }
+  }
+  lds_barrier();
+}
+
+template <int NL, int FMT>
+__global__ __launch_bounds__(WGB) void kc_bin_reads_kernel(ExtractArgs a, uint64_t ntiles, uint64_t *ctrs) {
+  extern __shared__ __align__(16) uint8_t smem[];
+  L1LDS &L = *reinterpret_cast<L1LDS *>(smem);
+  uint64_t *sorted = reinterpret_cast<uint64_t *>(smem + ((sizeof(L1LDS) + 15) & ~size_t(15)));
+  constexpr int RPOS = Rnd<NL>::RPOS_READS;
+  const int tid = threadIdx.x, q = tid >> 8, qt = tid & (TPB - 1);
+  const uint32_t P = a.rank_n;
+  if ((uint32_t)tid < PMAX) {
+    L.sp.hist[0][tid] = 0;
+    L.sp.hist[1][tid] = 0;
+  }
+  __syncthreads();
+  const int64_t lo = a.align, hi = (int64_t)a.align + (int64_t)a.total;
+  const uint64_t nsuper = (ntiles + QUARTERS - 1) / QUARTERS;
+  int buf = 0;
+  for (uint64_t st = blockIdx.x; st < nsuper; st += gridDim.x) {
+    const uint64_t tile = st * QUARTERS + q;
+    const bool active = tile < ntiles;
+    const int64_t T0 = (int64_t)(a.tile0 + tile) * TILE;
+    stage_tile<FMT>(L.tile[q], a, T0, ctrs, qt, (active && FMT == FMT_READS) ? a.tile_first[tile] : 0, active);
+#pragma unroll 1
+    for (int round = 0; round < PPT / RPOS; round++) {
+      uint64_t rec[RPOS][NL];
+      uint32_t br[RPOS];
+#pragma unroll
+      for (int j = 0; j < RPOS; j++) {
+        const int off = (round * RPOS + j) * TPB + qt;
+        const int64_t x = T0 + off;
+        uint64_t h = 0;
+        const bool valid = active && (x > lo) && (x + a.k < hi) && tile_kmer<NL>(L.tile[q], PRE + off, a.k, rec[j], h);
+        br[j] = ~0u;
+        if (valid) {
+          const uint32_t b = kc_owner_of_hash(h, P);
+          const uint32_t rank = atomicAdd(&L.sp.hist[buf][b], 1u);
+          br[j] = b | (rank << 10);
+        }
+      }
+      lds_barrier();
+      split_round_flat<NL, RPOS>(L.sp, sorted, buf, P, rec, br, a.records, a.seg_capacity, ctrs + CTR_BIN0, ctrs + CTR_OVERFLOW,
+                                 [&](uint64_t h) { return kc_owner_of_hash(h, P); });
+      buf ^= 1;
+    }
+  }
+}
+
 // ---- level 1 from records (receiver side of the shard exchange) -------------------------------------
 struct L1RLDS {
   SplitLDS sp;

@@ -376,7 +376,7 @@ __global__ void kc_tile_first_kernel(const uint64_t *offsets, uint64_t nreads, u
 }
 
 // raw k-mers of the block: sum over reads of max(0, len-k+1) (kcount.cpp:78,86)
-__global__ void kc_read_stats_kernel(const uint64_t *offsets, uint64_t nreads, int k, uint64_t *ctrs) {
+__global__ void kc_read_stats_kernel(const uint64_t *offsets, uint64_t nreads, int k, uint64_t *ctrs, uint32_t count_expect) {
   uint64_t acc = 0, exp = 0;
   const uint64_t stride = (uint64_t)gridDim.x * blockDim.x;
   for (uint64_t r = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x; r < nreads; r += stride) {
@@ -389,11 +389,11 @@ __global__ void kc_read_stats_kernel(const uint64_t *offsets, uint64_t nreads, i
     exp += __shfl_down(exp, o);
   }
   if (lane_id() == 0 && acc) atomicAdd((unsigned long long *)&ctrs[CTR_RAW_KMERS], (unsigned long long)acc);
-  if (lane_id() == 0 && exp) atomicAdd((unsigned long long *)&ctrs[CTR_EXPECT], (unsigned long long)exp);
+  if (count_expect && lane_id() == 0 && exp) atomicAdd((unsigned long long *)&ctrs[CTR_EXPECT], (unsigned long long)exp);
 }
 
 // the same for a '_'-joined block: count runs of non-separator bytes
-__global__ void kc_seqblock_stats_kernel(const uint8_t *seqs, uint64_t len, int k, uint64_t *ctrs) {
+__global__ void kc_seqblock_stats_kernel(const uint8_t *seqs, uint64_t len, int k, uint64_t *ctrs, uint32_t count_expect) {
   // one thread per byte that ends a run (next byte is '_' or end): walks back to the run start
   uint64_t acc = 0, exp = 0;
   const uint64_t stride = (uint64_t)gridDim.x * blockDim.x;
@@ -411,7 +411,7 @@ __global__ void kc_seqblock_stats_kernel(const uint8_t *seqs, uint64_t len, int 
     exp += __shfl_down(exp, o);
   }
   if (lane_id() == 0 && acc) atomicAdd((unsigned long long *)&ctrs[CTR_RAW_KMERS], (unsigned long long)acc);
-  if (lane_id() == 0 && exp) atomicAdd((unsigned long long *)&ctrs[CTR_EXPECT], (unsigned long long)exp);
+  if (count_expect && lane_id() == 0 && exp) atomicAdd((unsigned long long *)&ctrs[CTR_EXPECT], (unsigned long long)exp);
 }
 
 // ---- finalize ----------------------------------------------------------------------------------

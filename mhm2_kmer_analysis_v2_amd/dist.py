@@ -20,10 +20,10 @@ def exchange_counts(send_counts, group=None):
     return recv
 
 
-def exchange_records(send, send_counts, recv_counts, seg_capacity, num_longs, recv=None, group=None):
-    """send: int64 tensor laid out as world segments of seg_capacity records (num_longs words each), the
-    first send_counts[d] records of segment d being valid.  Returns (recv tensor, n_received): the received
-    records packed back to back."""
+def start_exchange(send, send_counts, recv_counts, seg_capacity, num_longs, recv=None, group=None):
+    """Begin the all-to-all-v of one block.  send: int64 tensor laid out as world segments of seg_capacity records
+    (num_longs words each), the first send_counts[d] records of segment d being valid.  Returns
+    (works, recv tensor, n_received): the received records packed back to back once every work has been waited for."""
     world = dist.get_world_size(group)
     sc = [int(x) for x in send_counts.tolist()]
     rc = [int(x) for x in recv_counts.tolist()]
@@ -44,13 +44,20 @@ def exchange_records(send, send_counts, recv_counts, seg_capacity, num_longs, re
         if d == me:
             dst.copy_(src)
             continue
+        peer = dist.get_global_rank(group, d) if group is not None else d
         if rc[d]:
-            ops.append(dist.P2POp(dist.irecv, dst, dist.get_global_rank(group, d) if group is not None else d, group))
+            ops.append(dist.P2POp(dist.irecv, dst, peer, group))
         if sc[d]:
-            ops.append(dist.P2POp(dist.isend, src, dist.get_global_rank(group, d) if group is not None else d, group))
-    if ops:
-        for w in dist.batch_isend_irecv(ops):
-            w.wait()
+            ops.append(dist.P2POp(dist.isend, src, peer, group))
+    works = dist.batch_isend_irecv(ops) if ops else []
+    return works, recv, total
+
+
+def exchange_records(send, send_counts, recv_counts, seg_capacity, num_longs, recv=None, group=None):
+    """Blocking form of start_exchange."""
+    works, recv, total = start_exchange(send, send_counts, recv_counts, seg_capacity, num_longs, recv, group)
+    for w in works:
+        w.wait()
     return recv, total
 
 
@@ -58,7 +65,10 @@ class ShardedKmerAnalysis:
     """count_kmers + flush_updates + finish_updates (src/kcount/kcount.cpp:54-104,142-161) across the ranks
     of one node.  `extract(block, send, seg_capacity) -> counts` and `insert(recv, n)` are the two device
     entry points (KmerCounter.extract_partition / insert_records on the GPU; the CPU tests plug in stand-ins
-    so that the exchange logic itself is what they exercise)."""
+    so that the exchange logic itself is what they exercise).
+
+    Two send and two receive buffers: while block i travels (RCCL's own stream), block i-1 is inserted and
+    block i+1 is extracted on the compute stream."""
 
     def __init__(self, extract, insert, num_longs, seg_capacity, device, group=None):
         self.extract, self.insert = extract, insert
@@ -66,18 +76,37 @@ class ShardedKmerAnalysis:
         self.group = group
         self.world = dist.get_world_size(group)
         self.device = device
-        self.send = torch.zeros(self.world * seg_capacity * num_longs, dtype=torch.int64, device=device)
-        self.recv = None
+        self.send = [torch.zeros(self.world * seg_capacity * num_longs, dtype=torch.int64, device=device) for _ in range(2)]
+        self.recv = [None, None]
+        self.pending = None
+        self.i = 0
         self.sent = 0
         self.received = 0
 
-    def add_block(self, block):
-        counts = self.extract(block, self.send, self.seg)
-        sc = torch.as_tensor([int(c) for c in counts], dtype=torch.int64, device=self.device)
-        rc = exchange_counts(sc, self.group)
-        self.recv, n = exchange_records(self.send, sc.cpu(), rc.cpu(), self.seg, self.nl, self.recv, self.group)
+    def _complete(self):
+        if self.pending is None:
+            return 0
+        works, recv, n = self.pending
+        self.pending = None
+        for w in works:
+            w.wait()
         if n:
-            self.insert(self.recv, n)
-        self.sent += int(sc.sum())
+            self.insert(recv, n)
         self.received += n
         return n
+
+    def add_block(self, block):
+        b = self.i % 2
+        self.i += 1
+        counts = self.extract(block, self.send[b], self.seg)
+        sc = torch.as_tensor([int(c) for c in counts], dtype=torch.int64, device=self.device)
+        rc = exchange_counts(sc, self.group)
+        works, self.recv[b], n = start_exchange(self.send[b], sc.cpu(), rc.cpu(), self.seg, self.nl, self.recv[b], self.group)
+        self._complete()  # the previous block: its transfer has had this block's extraction to finish
+        self.pending = (works, self.recv[b], n)
+        self.sent += int(sc.sum())
+        return n
+
+    def finish(self):
+        """Wait for and insert the last block in flight (call before finalize)."""
+        return self._complete()

@@ -141,6 +141,14 @@ int kc_submit_reads(kc_ctx *ctx, const uint8_t *bases, const uint8_t *quals, con
                     int on_device);
 
 /*
+ * The same from the reference's in-memory read cache, fed to the device as it is stored: one byte per base,
+ * low 3 bits = A0 C1 G2 T3 N4, high 5 bits = min(quality - qual_offset, 31) (PackedRead,
+ * src/packed_reads.cpp:99-126), read r = packed[offsets[r], offsets[r+1]).  Saves count_kmers the per-read
+ * unpack into three strings (src/kcount/kcount.cpp:76-85, packed_reads.cpp:196-208) and half the input bytes.
+ */
+int kc_submit_packed_reads(kc_ctx *ctx, const uint8_t *packed, const uint64_t *offsets, uint64_t nreads, int on_device);
+
+/*
  * ParseAndPackGPUDriver::process_seq_block input format
  * (src/kcount/kcount_gpu.cpp:167-180, parse_and_pack.cpp:281-319): reads already
  * case-masked (lowercase = low quality) and joined by '_'.

@@ -66,6 +66,7 @@ SYMBOLS = {
     "kc_set_stream": (C.c_int, [C.c_void_p, C.c_void_p]),
     "kc_reset": (C.c_int, [C.c_void_p, C.c_int]),
     "kc_submit_reads": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_uint64, C.c_int]),
+    "kc_submit_packed_reads": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_uint64, C.c_int]),
     "kc_submit_seq_block": (C.c_int, [C.c_void_p, C.c_void_p, C.c_uint64, C.c_int]),
     "kc_extract_partition": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_uint64, C.c_int, C.c_void_p,
                                        C.c_uint64, C.c_void_p]),

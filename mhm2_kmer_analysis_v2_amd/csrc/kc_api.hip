@@ -530,6 +530,14 @@ static int launch_l1_reads(kc_ctx *c, const ExtractArgs &a, uint64_t ntiles, int
       default: return launch_l1_reads_t<4, FMT_READS>(c, a, ntiles);
     }
   }
+  if (fmt == FMT_PACKED) {
+    switch (c->nl) {
+      case 1: return launch_l1_reads_t<1, FMT_PACKED>(c, a, ntiles);
+      case 2: return launch_l1_reads_t<2, FMT_PACKED>(c, a, ntiles);
+      case 3: return launch_l1_reads_t<3, FMT_PACKED>(c, a, ntiles);
+      default: return launch_l1_reads_t<4, FMT_PACKED>(c, a, ntiles);
+    }
+  }
   switch (c->nl) {
     case 1: return launch_l1_reads_t<1, FMT_SEQBLOCK>(c, a, ntiles);
     case 2: return launch_l1_reads_t<2, FMT_SEQBLOCK>(c, a, ntiles);
@@ -557,6 +565,14 @@ static int launch_bin_reads(kc_ctx *c, const ExtractArgs &a, uint64_t ntiles, in
       case 2: return launch_bin_reads_t<2, FMT_READS>(c, a, ntiles);
       case 3: return launch_bin_reads_t<3, FMT_READS>(c, a, ntiles);
       default: return launch_bin_reads_t<4, FMT_READS>(c, a, ntiles);
+    }
+  }
+  if (fmt == FMT_PACKED) {
+    switch (c->nl) {
+      case 1: return launch_bin_reads_t<1, FMT_PACKED>(c, a, ntiles);
+      case 2: return launch_bin_reads_t<2, FMT_PACKED>(c, a, ntiles);
+      case 3: return launch_bin_reads_t<3, FMT_PACKED>(c, a, ntiles);
+      default: return launch_bin_reads_t<4, FMT_PACKED>(c, a, ntiles);
     }
   }
   switch (c->nl) {
@@ -645,6 +661,7 @@ static void launch_extract(kc_ctx *c, const ExtractArgs &a, unsigned ntiles, int
   KernelTimer kt(c, mode == MODE_INSERT ? KT_EXTRACT_INSERT : KT_EXTRACT_BIN);
   if (mode == MODE_INSERT) {
     if (fmt == FMT_READS) launch_extract_m<MODE_INSERT, FMT_READS>(c, a, ntiles);
+    else if (fmt == FMT_PACKED) launch_extract_m<MODE_INSERT, FMT_PACKED>(c, a, ntiles);
     else launch_extract_m<MODE_INSERT, FMT_SEQBLOCK>(c, a, ntiles);
   } else {
     if (fmt == FMT_READS) launch_extract_m<MODE_BIN, FMT_READS>(c, a, ntiles);
@@ -665,8 +682,8 @@ static int run_extract_device(kc_ctx *c, const uint8_t *bases, const uint8_t *qu
   if (fmt == FMT_READS) {
     a.quals = quals - a.align;
     a.quals_vector_ok = (((uintptr_t)a.quals & 15u) == 0) ? 1u : 0u;
-    a.offsets = d_offsets;
   }
+  if (fmt != FMT_SEQBLOCK) a.offsets = d_offsets;
   a.nreads = nreads;
   a.total = total;
   a.k = c->k;
@@ -710,7 +727,7 @@ static int run_extract_device(kc_ctx *c, const uint8_t *bases, const uint8_t *qu
       int rc = ensure_room(c, nt * TILE);
       if (rc) return rc;
     }
-    if (fmt == FMT_READS) {
+    if (fmt != FMT_SEQBLOCK) {
       int rc = ensure_tile_first(c, nt);
       if (rc) return rc;
       {
@@ -732,7 +749,7 @@ static int run_extract_device(kc_ctx *c, const uint8_t *bases, const uint8_t *qu
     }
     HIPCHK(hipGetLastError());
     t0 += nt;
-    if (fmt == FMT_READS && t0 < ntiles_total) HIPCHK(hipStreamSynchronize(c->stream));  // d_tile_first is reused
+    if (fmt != FMT_SEQBLOCK && t0 < ntiles_total) HIPCHK(hipStreamSynchronize(c->stream));  // d_tile_first is reused
   }
   return KC_OK;
 }
@@ -770,8 +787,8 @@ static int ensure_stage(kc_ctx *c, size_t bytes, size_t reads, bool need_quals) 
 
 // reads (either residence) through extract in `mode`
 static int submit_reads_impl(kc_ctx *c, const uint8_t *bases, const uint8_t *quals, const uint64_t *offsets, uint64_t nreads,
-                             int on_device, int mode, uint64_t *d_records, uint64_t seg_capacity) {
-  if (!c || (nreads && (!bases || !quals || !offsets))) return KC_ERR_INVALID_ARG;
+                             int on_device, int mode, uint64_t *d_records, uint64_t seg_capacity, int fmt = FMT_READS) {
+  if (!c || (nreads && (!bases || (fmt == FMT_READS && !quals) || !offsets))) return KC_ERR_INVALID_ARG;
   if ((c->finalized || c->bk_level2) && mode == MODE_INSERT) return KC_ERR_STATE;  // extraction alone never touches the table
   HIPCHK(hipSetDevice(c->cfg.device));
   if (!nreads) return KC_OK;
@@ -783,7 +800,7 @@ static int submit_reads_impl(kc_ctx *c, const uint8_t *bases, const uint8_t *qua
     if (ends[0] != 0) return KC_ERR_INVALID_ARG;  // offsets are relative to `bases`
     int rc = raw_kmer_stats(c, offsets, nreads, mode);
     if (rc) return rc;
-    rc = run_extract_device(c, bases, quals, offsets, nreads, ends[1], mode, FMT_READS, d_records, seg_capacity);
+    rc = run_extract_device(c, bases, quals, offsets, nreads, ends[1], mode, fmt, d_records, seg_capacity);
     if (rc) return rc;
     c->num_reads += nreads;
     c->num_bases += ends[1];
@@ -804,13 +821,12 @@ static int submit_reads_impl(kc_ctx *c, const uint8_t *bases, const uint8_t *qua
     // the previous block's kernels may still be reading the staging buffers
     HIPCHK(hipStreamSynchronize(c->stream));
     HIPCHK(hipMemcpyAsync(c->d_stage_bases, bases + offsets[r0], nb, hipMemcpyHostToDevice, c->stream));
-    HIPCHK(hipMemcpyAsync(c->d_stage_quals, quals + offsets[r0], nb, hipMemcpyHostToDevice, c->stream));
+    if (fmt == FMT_READS) HIPCHK(hipMemcpyAsync(c->d_stage_quals, quals + offsets[r0], nb, hipMemcpyHostToDevice, c->stream));
     HIPCHK(hipMemcpyAsync(c->d_stage_offsets, rel.data(), (nr + 1) * 8, hipMemcpyHostToDevice, c->stream));
     HIPCHK(hipStreamSynchronize(c->stream));  // rel is reused next trip
     rc = raw_kmer_stats(c, c->d_stage_offsets, nr, mode);
     if (rc) return rc;
-    rc = run_extract_device(c, c->d_stage_bases, c->d_stage_quals, c->d_stage_offsets, nr, nb, mode, FMT_READS, d_records,
-                            seg_capacity);
+    rc = run_extract_device(c, c->d_stage_bases, c->d_stage_quals, c->d_stage_offsets, nr, nb, mode, fmt, d_records, seg_capacity);
     if (rc) return rc;
     c->num_reads += nr;
     c->num_bases += nb;
@@ -822,6 +838,10 @@ static int submit_reads_impl(kc_ctx *c, const uint8_t *bases, const uint8_t *qua
 extern "C" int kc_submit_reads(kc_ctx *c, const uint8_t *bases, const uint8_t *quals, const uint64_t *offsets, uint64_t nreads,
                                int on_device) {
   return submit_reads_impl(c, bases, quals, offsets, nreads, on_device, MODE_INSERT, nullptr, 0);
+}
+
+extern "C" int kc_submit_packed_reads(kc_ctx *c, const uint8_t *packed, const uint64_t *offsets, uint64_t nreads, int on_device) {
+  return submit_reads_impl(c, packed, nullptr, offsets, nreads, on_device, MODE_INSERT, nullptr, 0, FMT_PACKED);
 }
 
 extern "C" int kc_submit_seq_block(kc_ctx *c, const char *seqs, uint64_t len, int on_device) {

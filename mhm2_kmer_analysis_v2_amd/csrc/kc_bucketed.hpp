@@ -290,7 +290,7 @@ __global__ __launch_bounds__(WGB) void kc_l1_reads_kernel(ExtractArgs a, Geom gm
     const uint64_t tile = st * QUARTERS + q;
     const bool active = tile < ntiles;
     const int64_t T0 = (int64_t)(a.tile0 + tile) * TILE;
-    stage_tile<FMT>(L.tile[q], a, T0, ctrs, qt, (active && FMT == FMT_READS) ? a.tile_first[tile] : 0, active);
+    stage_tile<FMT>(L.tile[q], a, T0, ctrs, qt, (active && FMT != FMT_SEQBLOCK) ? a.tile_first[tile] : 0, active);
 #pragma unroll 1
     for (int round = 0; round < PPT / RPOS; round++) {
       uint64_t rec[RPOS][NL];
@@ -395,7 +395,7 @@ __global__ __launch_bounds__(WGB) void kc_bin_reads_kernel(ExtractArgs a, uint64
     const uint64_t tile = st * QUARTERS + q;
     const bool active = tile < ntiles;
     const int64_t T0 = (int64_t)(a.tile0 + tile) * TILE;
-    stage_tile<FMT>(L.tile[q], a, T0, ctrs, qt, (active && FMT == FMT_READS) ? a.tile_first[tile] : 0, active);
+    stage_tile<FMT>(L.tile[q], a, T0, ctrs, qt, (active && FMT != FMT_SEQBLOCK) ? a.tile_first[tile] : 0, active);
 #pragma unroll 1
     for (int round = 0; round < PPT / RPOS; round++) {
       uint64_t rec[RPOS][NL];

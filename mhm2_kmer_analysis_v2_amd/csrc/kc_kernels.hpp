@@ -33,7 +33,9 @@ constexpr uint64_t KEY_EMPTY = ~0ULL;
 constexpr uint64_t KEY_BUSY = ~0ULL - 1;
 
 enum { MODE_INSERT = 0, MODE_BIN = 1 };
-enum { FMT_READS = 0, FMT_SEQBLOCK = 1 };
+// input formats: ASCII bases + qualities; the reference's '_'-joined case-masked block; the reference's read
+// cache bytes (3-bit base | 5-bit quality << 3, src/packed_reads.cpp:99-126)
+enum { FMT_READS = 0, FMT_SEQBLOCK = 1, FMT_PACKED = 2 };
 
 // device-side counters, one u64 each (host mirror in kc_api)
 enum {
@@ -154,6 +156,11 @@ __device__ __forceinline__ uint32_t pack4(uint32_t v) {  // 4 ASCII bytes -> 4 c
   return (c * 0x40100401u) >> 24;
 }
 
+__device__ __forceinline__ uint32_t pack4_cache(uint32_t v) {  // 4 read-cache bytes (base 0-4 = ACGTN) -> 4 codes, N -> G
+  uint32_t c = (v & 0x03030303u) | ((v >> 1) & 0x02020202u);
+  return (c * 0x40100401u) >> 24;
+}
+
 constexpr uint32_t BM_ACGT = (1u << 1) | (1u << 3) | (1u << 7) | (1u << 20);
 constexpr uint32_t BM_ACGTN = BM_ACGT | (1u << 14);
 __device__ __forceinline__ bool in_bitmap(uint32_t c, uint32_t bm) { return ((c & 0xC0u) == 0x40u) && ((bm >> (c & 31u)) & 1u); }
@@ -194,13 +201,20 @@ __device__ __forceinline__ void stage_tile(TileLDS &L, const ExtractArgs &a, int
         }
       }
     }
-    uint32_t code = (pack4(bw[0]) << 24) | (pack4(bw[1]) << 16) | (pack4(bw[2]) << 8) | pack4(bw[3]);
+    uint32_t code = FMT == FMT_PACKED ? (pack4_cache(bw[0]) << 24) | (pack4_cache(bw[1]) << 16) | (pack4_cache(bw[2]) << 8) | pack4_cache(bw[3])
+                                      : (pack4(bw[0]) << 24) | (pack4(bw[1]) << 16) | (pack4(bw[2]) << 8) | pack4(bw[3]);
     uint32_t okm = 0, sepm = 0;
 #pragma unroll
     for (int i = 0; i < 16; i++) {
       const uint32_t c = (bw[i >> 2] >> (8 * (i & 3))) & 0xFFu;
       const bool real = full || (any && (X0 + i >= lo) && (X0 + i < hi));
       bool hq;
+      if (FMT == FMT_PACKED) {
+        hq = (c >> 3) >= KC_QUAL_CUTOFF;                      // S2 on the stored quality (already relative to qual_offset)
+        if (real && (c & 7u) > 4u) bad = true;
+        if (real && hq && (c & 7u) < 4u) okm |= 1u << i;
+        continue;
+      }
       if (FMT == FMT_READS) {
         const int q = (int)((qw[i >> 2] >> (8 * (i & 3))) & 0xFFu);
         hq = q >= a.qual_cut;                                 // S2
@@ -222,7 +236,7 @@ __device__ __forceinline__ void stage_tile(TileLDS &L, const ExtractArgs &a, int
       if (bits >> 32) atomicOr(&L.gap[(g >> 1) + 1], (uint32_t)(bits >> 32));
     }
   }
-  if (FMT == FMT_READS) {
+  if (FMT != FMT_SEQBLOCK) {
     // boundaries from the read offsets (the end of the data is offsets[nreads])
     const int64_t first = T0, last = T0 + TILE + a.k;  // gaps that any window of this tile can contain
     for (uint64_t r = tile_first_read + tid; r <= a.nreads; r += TPB) {
@@ -298,7 +312,7 @@ template <int NL, int MODE, int FMT>
 __global__ __launch_bounds__(TPB) void kc_extract_kernel(ExtractArgs a, Table t, uint64_t *ctrs) {
   __shared__ TileLDS L;
   const int64_t T0 = (int64_t)(a.tile0 + blockIdx.x) * TILE;
-  stage_tile<FMT>(L, a, T0, ctrs, threadIdx.x, FMT == FMT_READS ? a.tile_first[blockIdx.x] : 0, true);
+  stage_tile<FMT>(L, a, T0, ctrs, threadIdx.x, FMT != FMT_SEQBLOCK ? a.tile_first[blockIdx.x] : 0, true);
   const int64_t lo = a.align, hi = (int64_t)a.align + (int64_t)a.total;
   uint32_t n_ins = 0;
 #pragma unroll 1

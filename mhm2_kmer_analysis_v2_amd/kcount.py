@@ -115,6 +115,13 @@ class KmerCounter:
         n = (len(offsets) - 1) if nreads is None else nreads
         check(lib().kc_submit_reads(self._h, pb, pq, po, n, 1 if dev else 0), "kc_submit_reads")
 
+    def submit_packed_reads(self, packed, offsets, nreads=None):
+        """PackedRead bytes (base | quality<<3, src/packed_reads.cpp:99-126) + offsets."""
+        pp, dev = _ptr(packed)
+        po, _ = _ptr(offsets)
+        n = (len(offsets) - 1) if nreads is None else nreads
+        check(lib().kc_submit_packed_reads(self._h, pp, po, n, 1 if dev else 0), "kc_submit_packed_reads")
+
     def submit_seq_block(self, seqs, length=None):
         if isinstance(seqs, (bytes, bytearray)):
             buf = np.frombuffer(bytes(seqs), dtype=np.uint8)

@@ -363,3 +363,41 @@ def test_heavy_hitter_kmers():
         with pkg.KmerCounter(k, tuning=tuning) as kc:
             kc.submit_reads(b, q, offs)
             assert_same(kc.sorted_results(), want)
+
+
+def pack_reads(reads, quals, qual_offset=33):
+    """The reference's read cache bytes (PackedRead, src/packed_reads.cpp:99-126): base | min(q - offset, 31) << 3."""
+    code = {"A": 0, "C": 1, "G": 2, "T": 3, "N": 4}
+    out = bytearray()
+    for r, q in zip(reads, quals):
+        out.extend(code[c] | (min(ord(x) - qual_offset, 31) << 3) for c, x in zip(r, q))
+    return np.frombuffer(bytes(out), dtype=np.uint8).copy()
+
+
+@pytest.mark.parametrize("k", [21, 51])
+@pytest.mark.parametrize("tuning", [None, dict(mode=1)], ids=["bucketed", "table"])
+def test_packed_reads_ingest_matches_oracle(k, tuning):
+    import torch
+    rng = np.random.default_rng(40 + k)
+    reads, quals = random_reads(rng, 1200, min_len=k - 2, max_len=k + 120, genome_len=2500)
+    b, q, offs = arrays(reads, quals)
+    want, _, wst = oracle_run(b, q, offs, k)
+    packed = pack_reads(reads, quals)
+    with pkg.KmerCounter(k, tuning=tuning) as kc:  # host-resident
+        kc.submit_packed_reads(packed, offs)
+        got = kc.sorted_results()
+        st = kc.stats()
+    assert_same(got, want)
+    assert st["raw_kmers"] == wst["raw_kmers"] and st["num_unique"] == wst["unique"]
+    with pkg.KmerCounter(k, tuning=tuning) as kc:  # device-resident, odd alignment
+        dp = torch.zeros(len(packed) + 32, dtype=torch.uint8, device="cuda")
+        dp[5:5 + len(packed)] = torch.from_numpy(packed).cuda()
+        kc.submit_packed_reads(dp[5:], torch.from_numpy(offs.astype(np.int64)).cuda(), nreads=len(reads))
+        assert_same(kc.sorted_results(), want)
+    with pkg.KmerCounter(k, tuning=tuning) as kc:  # a base code above 4 is an error
+        bad = packed.copy()
+        bad[100] = (bad[100] & 0xF8) | 6
+        with pytest.raises(pkg.KcError) as e:
+            kc.submit_packed_reads(bad, offs)
+            kc.results()
+        assert e.value.status == -7

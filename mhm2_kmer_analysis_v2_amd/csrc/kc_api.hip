@@ -1055,6 +1055,12 @@ static int bk_level2_t(kc_ctx *c) {
   HIPCHK(hipGetLastError());
   rc = sync_cb(c);
   if (rc) return rc;
+#ifdef KC_STAMPS
+  fprintf(stderr, "l2 kernel cycles (thread 0, summed over workgroups): load+hist %llu barrierA %llu scan+reserve %llu scatter %llu copyout %llu\n",
+          (unsigned long long)c->h_cb[8], (unsigned long long)c->h_cb[9], (unsigned long long)c->h_cb[10],
+          (unsigned long long)c->h_cb[11], (unsigned long long)c->h_cb[12]);
+  HIPCHK(hipMemsetAsync(c->d_cb + 8, 0, 8 * 8, c->stream));
+#endif
   const uint64_t n1 = std::min<uint64_t>(c->h_cb[CB_OVF1], c->bb.ovf1_cap);
   if (n1) {
     hipLaunchKernelGGL(kc_ovf1_to_regions_kernel<NL>, dim3((unsigned)((n1 + 255) / 256)), dim3(256), 0, c->stream, c->gm, c->bb, n1, c->d_cb);
@@ -1096,7 +1102,7 @@ static int bk_count_t(kc_ctx *c, const OutBufs &ob) {
   const unsigned per_cu = lds * 2 <= 160 * 1024 ? 2u : 1u;
   KernelTimer kt(c, KT_COUNT_REGIONS);
   hipLaunchKernelGGL(kern, dim3((unsigned)std::min<uint64_t>(R, (uint64_t)c->num_cus * per_cu)), dim3(WGB), lds, c->stream, c->gm, c->bb,
-                     ob, c->cfg.dmin_thres, c->d_ctrs, c->d_cb, (uint32_t)(getenv("KC_DEBUG_COUNT") ? atoi(getenv("KC_DEBUG_COUNT")) : 0));
+                     ob, c->cfg.dmin_thres, c->d_ctrs, c->d_cb);
   return KC_OK;
 }
 
@@ -1189,12 +1195,12 @@ static int bk_finalize(kc_ctx *c) {
     if (rc) return rc;
     rc = sync_ctrs(c);
     if (rc) return rc;
-    if (getenv("KC_DEBUG_COUNT") && (atoi(getenv("KC_DEBUG_COUNT")) & 512)) {  // diagnostic stamps of kc_count_kernel
-      (void)sync_cb(c);
-      fprintf(stderr, "count kernel cycles (workgroup wave 0, summed over %d workgroups): zero %llu insert %llu satscan %llu vote %llu write %llu\n",
-              c->num_cus, (unsigned long long)c->h_cb[8], (unsigned long long)c->h_cb[9], (unsigned long long)c->h_cb[10],
-              (unsigned long long)c->h_cb[11], (unsigned long long)c->h_cb[12]);
-    }
+#ifdef KC_STAMPS
+    (void)sync_cb(c);
+    fprintf(stderr, "count kernel cycles (thread 0, summed over workgroups): zero %llu insert %llu satscan %llu vote %llu write %llu\n",
+            (unsigned long long)c->h_cb[8], (unsigned long long)c->h_cb[9], (unsigned long long)c->h_cb[10],
+            (unsigned long long)c->h_cb[11], (unsigned long long)c->h_cb[12]);
+#endif
     if (c->h_ctrs[CTR_OUT] <= c->out_cap) break;
     cap = c->h_ctrs[CTR_OUT];  // the pass only counted past the end: run it again with exactly enough room
   }

@@ -95,7 +95,6 @@ __device__ __forceinline__ void lds_barrier() { asm volatile("s_waitcnt lgkmcnt(
 // ---- workgroup exclusive scan over WGB values --------------------------------------------------
 struct ScanLDS {
   uint32_t wsum[32];
-  uint32_t wpre[32];
   uint32_t total;
 };
 
@@ -108,20 +107,20 @@ __device__ __forceinline__ uint32_t wave_incl_scan(uint32_t v) {
   return v;
 }
 
-// every thread of the workgroup calls this; returns the exclusive prefix of v, total in S.total (valid after return)
+// every thread of the workgroup calls this; returns the exclusive prefix of v, total in S.total (valid after the
+// caller's next barrier).  One barrier inside: every wave scans the 16 wave totals itself instead of waiting for
+// wave 0 to do it.
 __device__ __forceinline__ uint32_t block_excl_scan(uint32_t v, ScanLDS &S) {
   const int tid = threadIdx.x, wave = tid >> 6;
   const uint32_t incl = wave_incl_scan(v);
   if (lane_id() == 63) S.wsum[wave] = incl;
   lds_barrier();
-  if (tid < 64) {
-    const uint32_t w = (tid < WGB / 64) ? S.wsum[tid] : 0;
-    const uint32_t wi = wave_incl_scan(w);
-    if (tid < 32) S.wpre[tid] = wi - w;
-    if (tid == WGB / 64 - 1) S.total = wi;
-  }
-  lds_barrier();
-  return incl - v + S.wpre[wave];
+  const uint32_t w = (lane_id() < WGB / 64) ? S.wsum[lane_id()] : 0u;
+  const uint32_t wi = wave_incl_scan(w);
+  const uint32_t wave_pre = __shfl(wi - w, wave);             // exclusive prefix of this wave's total
+  const uint32_t total = __shfl(wi, WGB / 64 - 1);            // shuffles outside any branch: every lane takes part
+  if (tid == 0) S.total = total;
+  return incl - v + wave_pre;
 }
 
 // ---- multisplit of one round of records held in registers ---------------------------------------
@@ -137,7 +136,22 @@ struct SplitLDS {
 };
 
 // where the destinations of the current owner live
+#ifdef KC_STAMPS
+#define KC_SPLIT_STAMP(k)                                                                 \
+  if (threadIdx.x == 0 && D.stamps) {                                                     \
+    const unsigned long long tn_ = __builtin_amdgcn_s_memtime();                          \
+    atomicAdd((unsigned long long *)&D.stamps[k], tn_ - *D.tprev);                        \
+    *D.tprev = tn_;                                                                       \
+  }
+#else
+#define KC_SPLIT_STAMP(k)
+#endif
+
 struct ChainDest {
+#ifdef KC_STAMPS
+  uint64_t *stamps;                 // diagnostic builds: cb + 8
+  unsigned long long *tprev;        // thread 0's last stamp
+#endif
   uint64_t *arena;      // chunk id c starts at arena + (c << log2CH) * NL
   uint32_t *chain;      // destination b's chain: chain[b*LMAX + i]
   uint32_t log2CH, LMAX;
@@ -160,6 +174,7 @@ __device__ __forceinline__ void split_round(SplitLDS &L, uint64_t *sorted, int b
                                             OvfFn overflow) {
   const int tid = threadIdx.x;
   uint32_t *H = L.hist[buf];
+  KC_SPLIT_STAMP(1)  // barrier after the histogram
   const uint32_t v = ((uint32_t)tid < P) ? H[tid] : 0u;
   const uint32_t excl = block_excl_scan(v, L.scan);
   const uint32_t CHm = (1u << D.log2CH) - 1u;
@@ -190,6 +205,7 @@ __device__ __forceinline__ void split_round(SplitLDS &L, uint64_t *sorted, int b
     L.hist[buf ^ 1][tid] = 0;  // next round's histogram
   }
   lds_barrier();
+  KC_SPLIT_STAMP(2)  // scan + reserve
   const uint32_t total = L.scan.total;
 #pragma unroll
   for (int j = 0; j < R; j++) {
@@ -201,24 +217,42 @@ __device__ __forceinline__ void split_round(SplitLDS &L, uint64_t *sorted, int b
     }
   }
   lds_barrier();
-  for (uint32_t i = tid; i < total; i += WGB) {
-    uint64_t r[NL];
+  KC_SPLIT_STAMP(3)  // scatter to LDS
+  // copy out, U elements per thread and trip: the LDS reads, the hashes and the bucket look-ups of the U elements are
+  // independent chains the hardware can overlap (one element per trip is a single long dependent chain per wave)
+  constexpr int U = NL == 1 ? 4 : 2;
+  for (uint32_t i0 = tid; i0 < total; i0 += U * WGB) {
+    uint64_t r[U][NL];
+    uint32_t b[U];
 #pragma unroll
-    for (int w = 0; w < NL; w++) r[w] = sorted[(size_t)i * NL + w];
-    const uint32_t b = bucket_of(rec_hash<NL>(r));
-    const uint32_t j = i - L.offs[b];
-    if (j < H[b]) {
-      const uint32_t db = L.dbase[b], p = db + j, ci = p >> D.log2CH;
-      // the run starts inside the chain's old last chunk (c0) unless it starts chunk-aligned; later chunks are new
-      const uint32_t cid = ((db & CHm) && ci == (db >> D.log2CH)) ? L.c0[b] : L.nb[b] + ci;
-      uint64_t *d = D.arena + (((size_t)cid << D.log2CH) + (p & CHm)) * NL;
+    for (int u = 0; u < U; u++) {
+      const uint32_t i = i0 + u * WGB;
+      const uint32_t ii = i < total ? i : i0;  // in range: i0 < total
 #pragma unroll
-      for (int w = 0; w < NL; w++) d[w] = r[w];
-    } else {
-      overflow(b, r);
+      for (int w = 0; w < NL; w++) r[u][w] = sorted[(size_t)ii * NL + w];
+    }
+#pragma unroll
+    for (int u = 0; u < U; u++) b[u] = bucket_of(rec_hash<NL>(r[u]));
+#pragma unroll
+    for (int u = 0; u < U; u++) {
+      const uint32_t i = i0 + u * WGB;
+      if (i >= total) break;
+      const uint32_t j = i - L.offs[b[u]];
+      if (j < H[b[u]]) {
+        const uint32_t db = L.dbase[b[u]], p = db + j, ci = p >> D.log2CH;
+        // the run starts inside the chain's old last chunk (c0) unless it starts chunk-aligned; later chunks are new
+        const uint32_t cid = ((db & CHm) && ci == (db >> D.log2CH)) ? L.c0[b[u]] : L.nb[b[u]] + ci;
+        uint64_t *d = D.arena + (((size_t)cid << D.log2CH) + (p & CHm)) * NL;
+#pragma unroll
+        for (int w = 0; w < NL; w++) d[w] = r[u][w];
+      } else {
+        overflow(b[u], r[u]);
+      }
     }
   }
-  lds_barrier();
+  KC_SPLIT_STAMP(4)  // copy-out
+  // no barrier here: the next round only touches the other histogram buffer and registers until its own first
+  // barrier, which every wave reaches after finishing this copy-out
 }
 
 // load the persistent state of this owner's P chains (before its first round)
@@ -249,6 +283,10 @@ struct L1LDS {
 template <int NL>
 __device__ __forceinline__ ChainDest l1_dest(const Geom &gm, const BucketBufs &bb, uint32_t g) {
   ChainDest D;
+#ifdef KC_STAMPS
+  D.stamps = nullptr;
+  D.tprev = nullptr;
+#endif
   D.arena = bb.rec1 + (((size_t)g * gm.A1) << gm.log2CH1) * NL;
   D.chain = bb.chain1 + (size_t)g * gm.P1 * gm.L1MAX;
   D.log2CH = gm.log2CH1;
@@ -372,7 +410,6 @@ __device__ __forceinline__ void split_round_flat(SplitLDS &L, uint64_t *sorted, 
       *overflow_flag = 1;
     }
   }
-  lds_barrier();
 }
 
 template <int NL, int FMT>
@@ -535,6 +572,11 @@ __global__ __launch_bounds__(WGB) void kc_l2_split_kernel(Geom gm, BucketBufs bb
     D.LMAX = gm.L2MAX;
     D.arena_base = bb.base2[b1];
     D.arena_cap = bb.base2[b1 + 1] - bb.base2[b1];
+#ifdef KC_STAMPS
+    unsigned long long tprev_ = __builtin_amdgcn_s_memtime();
+    D.stamps = cb + 8;
+    D.tprev = &tprev_;
+#endif
     ChainState cst = split_load_state(L.sp, P2, nullptr, D.chain, D.LMAX, D.log2CH, D.arena_base, 0);
     __syncthreads();
     const uint32_t n = L.pre[G];
@@ -574,6 +616,7 @@ __global__ __launch_bounds__(WGB) void kc_l2_split_kernel(Geom gm, BucketBufs bb
           br[j] = b | (rank << 10);
         }
       }
+      KC_SPLIT_STAMP(0)  // wait for the records, issue the next loads, histogram
       lds_barrier();
       split_round<NL, RPOS>(
           L.sp, sorted, buf, P2, rec, br, D, cst, [&](uint64_t h) { return hash_b2(h, gm); },
@@ -747,27 +790,33 @@ __device__ __forceinline__ uint32_t lds_probe1(unsigned long long *claim, uint32
 // (clipped) counters, for tests of S5/S6; no statistics are touched.
 template <int NL, bool DUMP>
 __global__ __launch_bounds__(WGB) void kc_count_kernel(Geom gm, BucketBufs bb, OutBufs out, int dmin_thres, uint64_t *ctrs,
-                                                       uint64_t *cb, uint32_t dbg) {
+                                                       uint64_t *cb) {
   extern __shared__ __align__(16) uint8_t smem[];
   CountLDS<NL> &T = *reinterpret_cast<CountLDS<NL> *>(smem);
   const int tid = threadIdx.x;
   const uint32_t S = gm.S, SM = gm.S;
   const CountTab tb = count_tab<NL>(smem, S);
   const size_t R = (size_t)gm.P1 * gm.P2;
-  // diagnostic only (dbg & 512): wave 0 accumulates the cycles between the phase boundaries of every region into cb[8..]
+  // diagnostic builds only (-DKC_STAMPS): thread 0 accumulates the cycles between the phase boundaries of every region
+  // into cb[8..]; the shipped build has no stamp code at all
+#ifdef KC_STAMPS
   unsigned long long tacc[6] = {0, 0, 0, 0, 0, 0}, tprev = 0;
-  const bool stamp = (dbg & 512u) && tid == 0;
-#define KC_STAMP(k)                                        \
-  if (stamp) {                                             \
+  const bool stamp = tid == 0;
+#define KC_STAMP(k)                                             \
+  if (stamp) {                                                  \
     const unsigned long long tn = __builtin_amdgcn_s_memtime(); \
-    tacc[k] += tn - tprev;                                 \
-    tprev = tn;                                            \
+    tacc[k] += tn - tprev;                                      \
+    tprev = tn;                                                 \
   }
+#else
+#define KC_STAMP(k)
+#endif
   for (size_t r = blockIdx.x; r < R; r += gridDim.x) {
     const uint32_t n = bb.cnt2[r];
     if (n == 0 || bb.flag[r]) continue;  // uniform across the workgroup
+#ifdef KC_STAMPS
     if (stamp) tprev = __builtin_amdgcn_s_memtime();
-    if (!(dbg & 4u))
+#endif
     for (uint32_t s = tid; s < S; s += WGB) {
 #pragma unroll
       for (int w = 0; w < NL; w++) tb.keys[w * SM + s] = KEY_EMPTY;
@@ -809,7 +858,7 @@ __global__ __launch_bounds__(WGB) void kc_count_kernel(Geom gm, BucketBufs bb, O
 #pragma unroll
         for (int w = 0; w < NL; w++) rec[j][w] = src[j][w];
       if constexpr (NL == 1) {
-        if (!(dbg & 1u)) {
+        {
           uint32_t failed = 0;
 #pragma unroll
           for (int j = 0; j < BATCH; j++) {
@@ -856,10 +905,6 @@ __global__ __launch_bounds__(WGB) void kc_count_kernel(Geom gm, BucketBufs bb, O
     }
     KC_STAMP(2)  // saturation scan
     // S7 vote + S8 purge; survivors get a rank
-    if (dbg & 2u) {
-      __syncthreads();
-      continue;
-    }
     for (uint32_t s = tid; s < S; s += WGB) {
       uint32_t packed = ~0u;
       if (tb.keys[(NL - 1) * SM + s] != KEY_EMPTY) {
@@ -917,8 +962,10 @@ __global__ __launch_bounds__(WGB) void kc_count_kernel(Geom gm, BucketBufs bb, O
     __syncthreads();
     KC_STAMP(4)  // write out
   }
+#ifdef KC_STAMPS
   if (stamp)
     for (int k = 0; k < 5; k++) atomicAdd((unsigned long long *)&cb[8 + k], tacc[k]);
+#endif
 #undef KC_STAMP
 }
 

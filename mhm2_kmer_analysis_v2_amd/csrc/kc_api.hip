@@ -504,7 +504,10 @@ static int set_dyn_lds(K kernel, size_t bytes) {
   return KC_OK;
 }
 
-template <int NL> static size_t lds_l1_reads() { return ((sizeof(L1LDS) + 15) & ~size_t(15)) + Rnd<NL>::STAGE_READS; }
+// the sorted staging plus one uint16 bucket id per staged record
+template <int NL> static size_t lds_l1_reads() {
+  return ((sizeof(L1LDS) + 15) & ~size_t(15)) + Rnd<NL>::STAGE_READS + (size_t)WGB * Rnd<NL>::RPOS_READS * 2;
+}
 template <int NL> static size_t lds_l1_records() { return ((sizeof(L1RLDS) + 15) & ~size_t(15)) + Rnd<NL>::STAGE; }
 template <int NL> static size_t lds_l2() { return ((sizeof(L2LDS) + 15) & ~size_t(15)) + Rnd<NL>::STAGE; }
 
@@ -1079,6 +1082,13 @@ static int bk_build_regions(kc_ctx *c) {
     snprintf(g_last_error, sizeof(g_last_error), "k-mer buffer overflow lists exhausted: raise max_kmers_buffered");
     return KC_ERR_CAPACITY;
   }
+#ifdef KC_STAMPS
+  (void)sync_cb(c);
+  fprintf(stderr, "l1 kernel cycles (thread 0, summed over workgroups): extract+hist %llu barrierA %llu scan+reserve %llu scatter %llu copyout %llu stage %llu\n",
+          (unsigned long long)c->h_cb[8], (unsigned long long)c->h_cb[9], (unsigned long long)c->h_cb[10],
+          (unsigned long long)c->h_cb[11], (unsigned long long)c->h_cb[12], (unsigned long long)c->h_cb[13]);
+  HIPCHK(hipMemsetAsync(c->d_cb + 8, 0, 8 * 8, c->stream));
+#endif
   switch (c->nl) {
     case 1: rc = bk_level2_t<1>(c); break;
     case 2: rc = bk_level2_t<2>(c); break;

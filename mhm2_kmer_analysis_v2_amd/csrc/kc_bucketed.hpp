@@ -169,9 +169,11 @@ struct ChainState {
 // hist[buf] with LDS atomics (bucket | rank<<10 in br[], ~0 for "no record") and hit a barrier.
 //   bucket_of(hash) recomputes a record's bucket during copy-out; overflow(b, rec) takes what found no room
 template <int NL, int R, class BucketFn, class OvfFn>
-__device__ __forceinline__ void split_round(SplitLDS &L, uint64_t *sorted, int buf, uint32_t P, const uint64_t (&rec)[R][NL],
-                                            const uint32_t (&br)[R], const ChainDest &D, ChainState &st, BucketFn bucket_of,
-                                            OvfFn overflow) {
+__device__ __forceinline__ void split_round(SplitLDS &L, uint64_t *sorted, uint16_t *sbucket, int buf, uint32_t P,
+                                            const uint64_t (&rec)[R][NL], const uint32_t (&br)[R], const ChainDest &D, ChainState &st,
+                                            BucketFn bucket_of, OvfFn overflow) {
+  // sbucket: optional LDS array parallel to `sorted` that remembers each staged record's bucket, so that the copy-out
+  // need not hash the record again (null where the LDS has no room for it)
   const int tid = threadIdx.x;
   uint32_t *H = L.hist[buf];
   KC_SPLIT_STAMP(1)  // barrier after the histogram
@@ -214,6 +216,7 @@ __device__ __forceinline__ void split_round(SplitLDS &L, uint64_t *sorted, int b
       const uint32_t pos = L.offs[b] + rank;
 #pragma unroll
       for (int w = 0; w < NL; w++) sorted[(size_t)pos * NL + w] = rec[j][w];
+      if (sbucket) sbucket[pos] = (uint16_t)b;
     }
   }
   lds_barrier();
@@ -231,8 +234,16 @@ __device__ __forceinline__ void split_round(SplitLDS &L, uint64_t *sorted, int b
 #pragma unroll
       for (int w = 0; w < NL; w++) r[u][w] = sorted[(size_t)ii * NL + w];
     }
+    if (sbucket) {
 #pragma unroll
-    for (int u = 0; u < U; u++) b[u] = bucket_of(rec_hash<NL>(r[u]));
+      for (int u = 0; u < U; u++) {
+        const uint32_t i = i0 + u * WGB;
+        b[u] = sbucket[i < total ? i : i0];
+      }
+    } else {
+#pragma unroll
+      for (int u = 0; u < U; u++) b[u] = bucket_of(rec_hash<NL>(r[u]));
+    }
 #pragma unroll
     for (int u = 0; u < U; u++) {
       const uint32_t i = i0 + u * WGB;
@@ -313,22 +324,41 @@ __global__ __launch_bounds__(WGB) void kc_l1_reads_kernel(ExtractArgs a, Geom gm
   extern __shared__ __align__(16) uint8_t smem[];
   L1LDS &L = *reinterpret_cast<L1LDS *>(smem);
   uint64_t *sorted = reinterpret_cast<uint64_t *>(smem + ((sizeof(L1LDS) + 15) & ~size_t(15)));
+  uint16_t *sbucket = reinterpret_cast<uint16_t *>(smem + ((sizeof(L1LDS) + 15) & ~size_t(15)) + Rnd<NL>::STAGE_READS);
   constexpr int RPOS = Rnd<NL>::RPOS_READS;
   const int tid = threadIdx.x, q = tid >> 8, qt = tid & (TPB - 1);
   // writer id: launches rotate their first writer (rot) so that many small submits still spread evenly
   const uint32_t g = (blockIdx.x + rot) % gm.G, P1 = gm.P1;
-  const ChainDest D = l1_dest<NL>(gm, bb, g);
+  ChainDest D = l1_dest<NL>(gm, bb, g);
+#ifdef KC_STAMPS
+  unsigned long long tprev_ = __builtin_amdgcn_s_memtime();
+  D.stamps = cb + 8;
+  D.tprev = &tprev_;
+#endif
   ChainState cst = split_load_state(L.sp, P1, bb.cnt1 + (size_t)g * P1, D.chain, D.LMAX, D.log2CH, 0, bb.used1[g]);
   __syncthreads();
   const int64_t lo = a.align, hi = (int64_t)a.align + (int64_t)a.total;
   const uint64_t nsuper = (ntiles + QUARTERS - 1) / QUARTERS;
   uint32_t n_ins = 0;
   int buf = 0;
+  // the bytes of the next super-tile are on their way while this one is processed
+  TileRaw raw;
+  {
+    const uint64_t tile = (uint64_t)blockIdx.x * QUARTERS + q;
+    const bool active = blockIdx.x < nsuper && tile < ntiles;
+    tile_prefetch<FMT>(raw, a, (int64_t)(a.tile0 + tile) * TILE, qt, (active && FMT != FMT_SEQBLOCK) ? a.tile_first[tile] : 0, active);
+  }
   for (uint64_t st = blockIdx.x; st < nsuper; st += gridDim.x) {
     const uint64_t tile = st * QUARTERS + q;
     const bool active = tile < ntiles;
     const int64_t T0 = (int64_t)(a.tile0 + tile) * TILE;
-    stage_tile<FMT>(L.tile[q], a, T0, ctrs, qt, (active && FMT != FMT_SEQBLOCK) ? a.tile_first[tile] : 0, active);
+    tile_encode<FMT>(L.tile[q], raw, a, T0, ctrs, qt, active);
+    {
+      const uint64_t nst = st + gridDim.x, ntile = nst * QUARTERS + q;
+      const bool nactive = nst < nsuper && ntile < ntiles;
+      tile_prefetch<FMT>(raw, a, (int64_t)(a.tile0 + ntile) * TILE, qt, (nactive && FMT != FMT_SEQBLOCK) ? a.tile_first[ntile] : 0, nactive);
+    }
+    KC_SPLIT_STAMP(5)  // stage the tiles
 #pragma unroll 1
     for (int round = 0; round < PPT / RPOS; round++) {
       uint64_t rec[RPOS][NL];
@@ -348,9 +378,10 @@ __global__ __launch_bounds__(WGB) void kc_l1_reads_kernel(ExtractArgs a, Geom gm
           n_ins++;
         }
       }
+      KC_SPLIT_STAMP(0)  // cut the k-mers out of the tiles, histogram
       lds_barrier();
       split_round<NL, RPOS>(
-          L.sp, sorted, buf, P1, rec, br, D, cst, [&](uint64_t h) { return hash_b1(h, gm); },
+          L.sp, sorted, sbucket, buf, P1, rec, br, D, cst, [&](uint64_t h) { return hash_b1(h, gm); },
           [&](uint32_t, const uint64_t (&r)[NL]) { l1_overflow<NL>(bb, cb, r); });
       buf ^= 1;
     }
@@ -428,11 +459,23 @@ __global__ __launch_bounds__(WGB) void kc_bin_reads_kernel(ExtractArgs a, uint64
   const int64_t lo = a.align, hi = (int64_t)a.align + (int64_t)a.total;
   const uint64_t nsuper = (ntiles + QUARTERS - 1) / QUARTERS;
   int buf = 0;
+  // the bytes of the next super-tile are on their way while this one is processed
+  TileRaw raw;
+  {
+    const uint64_t tile = (uint64_t)blockIdx.x * QUARTERS + q;
+    const bool active = blockIdx.x < nsuper && tile < ntiles;
+    tile_prefetch<FMT>(raw, a, (int64_t)(a.tile0 + tile) * TILE, qt, (active && FMT != FMT_SEQBLOCK) ? a.tile_first[tile] : 0, active);
+  }
   for (uint64_t st = blockIdx.x; st < nsuper; st += gridDim.x) {
     const uint64_t tile = st * QUARTERS + q;
     const bool active = tile < ntiles;
     const int64_t T0 = (int64_t)(a.tile0 + tile) * TILE;
-    stage_tile<FMT>(L.tile[q], a, T0, ctrs, qt, (active && FMT != FMT_SEQBLOCK) ? a.tile_first[tile] : 0, active);
+    tile_encode<FMT>(L.tile[q], raw, a, T0, ctrs, qt, active);
+    {
+      const uint64_t nst = st + gridDim.x, ntile = nst * QUARTERS + q;
+      const bool nactive = nst < nsuper && ntile < ntiles;
+      tile_prefetch<FMT>(raw, a, (int64_t)(a.tile0 + ntile) * TILE, qt, (nactive && FMT != FMT_SEQBLOCK) ? a.tile_first[ntile] : 0, nactive);
+    }
 #pragma unroll 1
     for (int round = 0; round < PPT / RPOS; round++) {
       uint64_t rec[RPOS][NL];
@@ -497,7 +540,7 @@ __global__ __launch_bounds__(WGB) void kc_l1_records_kernel(const uint64_t *recs
     }
     lds_barrier();
     split_round<NL, RPOS>(
-        L.sp, sorted, buf, P1, rec, br, D, cst, [&](uint64_t h) { return hash_b1(h, gm); },
+        L.sp, sorted, nullptr, buf, P1, rec, br, D, cst, [&](uint64_t h) { return hash_b1(h, gm); },
         [&](uint32_t, const uint64_t (&r)[NL]) { l1_overflow<NL>(bb, cb, r); });
     buf ^= 1;
   }
@@ -619,7 +662,7 @@ __global__ __launch_bounds__(WGB) void kc_l2_split_kernel(Geom gm, BucketBufs bb
       KC_SPLIT_STAMP(0)  // wait for the records, issue the next loads, histogram
       lds_barrier();
       split_round<NL, RPOS>(
-          L.sp, sorted, buf, P2, rec, br, D, cst, [&](uint64_t h) { return hash_b2(h, gm); },
+          L.sp, sorted, nullptr, buf, P2, rec, br, D, cst, [&](uint64_t h) { return hash_b2(h, gm); },
           [&](uint32_t b, const uint64_t (&r)[NL]) {
             bb.flag[(size_t)b1 * P2 + b] = 1;
             const uint64_t o = atomicAdd((unsigned long long *)&cb[CB_OVF2], 1ULL);

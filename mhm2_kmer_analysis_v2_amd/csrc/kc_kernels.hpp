@@ -165,42 +165,76 @@ constexpr uint32_t BM_ACGT = (1u << 1) | (1u << 3) | (1u << 7) | (1u << 20);
 constexpr uint32_t BM_ACGTN = BM_ACGT | (1u << 14);
 __device__ __forceinline__ bool in_bitmap(uint32_t c, uint32_t bm) { return ((c & 0xC0u) == 0x40u) && ((bm >> (c & 31u)) & 1u); }
 
-// Stage the tile.  Aligned coordinate x = byte index from the 16-byte aligned base address; local
-// position lp = x - (T0 - PRE).
+// Staging a tile has two halves so that a kernel can keep the next tile's bytes in flight while it works on the
+// current one: tile_prefetch issues the global loads into registers (nothing waits on them), tile_encode turns
+// the registers into the LDS image.  Aligned coordinate x = byte index from the 16-byte aligned base address;
+// local position lp = x - (T0 - PRE).  Thread tid (0..TPB-1 of the TPB threads sharing the tile) owns the
+// 16-byte groups tid and tid + TPB.
+constexpr int GROUPS_PER_THREAD = (NGROUP + TPB - 1) / TPB;  // 2
+
+struct TileRaw {
+  uint32_t bw[GROUPS_PER_THREAD][4];
+  uint32_t qw[GROUPS_PER_THREAD][4];
+  uint64_t first_read;  // first read starting at or after the tile's first position
+  uint64_t off;         // offsets[first_read + tid], or ~0 past the end
+};
+
 template <int FMT>
-__device__ __forceinline__ void stage_tile(TileLDS &L, const ExtractArgs &a, int64_t T0, uint64_t *ctrs, int tid, uint64_t tile_first_read,
-                                           bool active) {
-  // tid: 0..TPB-1 within the TPB threads that share this tile; every thread of the workgroup reaches both barriers
+__device__ __forceinline__ void tile_prefetch(TileRaw &R, const ExtractArgs &a, int64_t T0, int tid, uint64_t tile_first_read, bool active) {
+  const int64_t lo = a.align, hi = (int64_t)a.align + (int64_t)a.total;  // real data is [lo, hi)
+#pragma unroll
+  for (int gi = 0; gi < GROUPS_PER_THREAD; gi++) {
+#pragma unroll
+    for (int w = 0; w < 4; w++) {
+      R.bw[gi][w] = 0;
+      R.qw[gi][w] = 0;
+    }
+    const int g = tid + gi * TPB;
+    const int64_t X0 = T0 - PRE + 16 * g;
+    if (active && g < NGROUP && (X0 + 16 > lo) && (X0 < hi)) {
+      // the 16-byte line holding the group is inside the allocation's aligned span whenever any
+      // of its bytes is real data, so the vector load is safe; bytes outside [lo,hi) are masked when encoding
+      const uint4 v = *reinterpret_cast<const uint4 *>(a.bases + X0);
+      R.bw[gi][0] = v.x; R.bw[gi][1] = v.y; R.bw[gi][2] = v.z; R.bw[gi][3] = v.w;
+      if (FMT == FMT_READS) {
+        if (a.quals_vector_ok) {
+          const uint4 q = *reinterpret_cast<const uint4 *>(a.quals + X0);
+          R.qw[gi][0] = q.x; R.qw[gi][1] = q.y; R.qw[gi][2] = q.z; R.qw[gi][3] = q.w;
+        } else {
+          for (int i = 0; i < 16; i++) {
+            const int64_t x = X0 + i;
+            if (x >= lo && x < hi) R.qw[gi][i >> 2] |= (uint32_t)a.quals[x] << (8 * (i & 3));
+          }
+        }
+      }
+    }
+  }
+  R.first_read = tile_first_read;
+  R.off = ~0ULL;
+  if (FMT != FMT_SEQBLOCK && active && tile_first_read + tid <= a.nreads) R.off = a.offsets[tile_first_read + tid];
+}
+
+template <int FMT>
+__device__ __forceinline__ void tile_encode(TileLDS &L, const TileRaw &R, const ExtractArgs &a, int64_t T0, uint64_t *ctrs, int tid,
+                                            bool active) {
+  // every thread of the workgroup reaches both barriers
   for (int i = tid; i < NWORD + 1; i += TPB) L.gap[i] = 0;
   __syncthreads();
   if (!active) {
     __syncthreads();
     return;
   }
-  const int64_t lo = a.align, hi = (int64_t)a.align + (int64_t)a.total;  // real data is [lo, hi)
+  const int64_t lo = a.align, hi = (int64_t)a.align + (int64_t)a.total;
   bool bad = false;
-  for (int g = tid; g < NGROUP; g += TPB) {
+#pragma unroll
+  for (int gi = 0; gi < GROUPS_PER_THREAD; gi++) {
+    const int g = tid + gi * TPB;
+    if (g >= NGROUP) break;
     const int64_t X0 = T0 - PRE + 16 * g;
-    uint32_t bw[4] = {0, 0, 0, 0}, qw[4] = {0, 0, 0, 0};
+    const uint32_t(&bw)[4] = R.bw[gi];
+    const uint32_t(&qw)[4] = R.qw[gi];
     const bool any = (X0 + 16 > lo) && (X0 < hi);
     const bool full = (X0 >= lo) && (X0 + 16 <= hi);
-    if (any) {
-      // the 16-byte line holding the group is inside the allocation's aligned span whenever any
-      // of its bytes is real data, so the vector load is safe; bytes outside [lo,hi) are masked below
-      uint4 v = *reinterpret_cast<const uint4 *>(a.bases + X0);
-      bw[0] = v.x; bw[1] = v.y; bw[2] = v.z; bw[3] = v.w;
-      if (FMT == FMT_READS) {
-        if (a.quals_vector_ok) {
-          uint4 q = *reinterpret_cast<const uint4 *>(a.quals + X0);
-          qw[0] = q.x; qw[1] = q.y; qw[2] = q.z; qw[3] = q.w;
-        } else {
-          for (int i = 0; i < 16; i++) {
-            int64_t x = X0 + i;
-            if (x >= lo && x < hi) qw[i >> 2] |= (uint32_t)a.quals[x] << (8 * (i & 3));
-          }
-        }
-      }
-    }
     uint32_t code = FMT == FMT_PACKED ? (pack4_cache(bw[0]) << 24) | (pack4_cache(bw[1]) << 16) | (pack4_cache(bw[2]) << 8) | pack4_cache(bw[3])
                                       : (pack4(bw[0]) << 24) | (pack4(bw[1]) << 16) | (pack4(bw[2]) << 8) | pack4(bw[3]);
     uint32_t okm = 0, sepm = 0;
@@ -237,13 +271,16 @@ __device__ __forceinline__ void stage_tile(TileLDS &L, const ExtractArgs &a, int
     }
   }
   if (FMT != FMT_SEQBLOCK) {
-    // boundaries from the read offsets (the end of the data is offsets[nreads])
+    // boundaries from the read offsets (the end of the data is offsets[nreads]); the first one of this thread
+    // came with the prefetch, more only when a tile holds over TPB reads
     const int64_t first = T0, last = T0 + TILE + a.k;  // gaps that any window of this tile can contain
-    for (uint64_t r = tile_first_read + tid; r <= a.nreads; r += TPB) {
-      int64_t s = (int64_t)a.offsets[r] + lo;
+    uint64_t off = R.off;
+    for (uint64_t r = R.first_read + tid; r <= a.nreads; r += TPB) {
+      if (r != R.first_read + tid) off = a.offsets[r];
+      const int64_t s = (int64_t)off + lo;
       if (s > last) break;
       if (s >= first) {
-        int lp = (int)(s - (T0 - PRE));
+        const int lp = (int)(s - (T0 - PRE));
         atomicOr(&L.gap[lp >> 5], 1u << (lp & 31));
       }
     }
@@ -257,6 +294,15 @@ __device__ __forceinline__ void stage_tile(TileLDS &L, const ExtractArgs &a, int
   }
   if (bad) ctrs[CTR_BAD_BASE] = 1;
   __syncthreads();
+}
+
+// both halves back to back (kernels that do not pipeline their tiles)
+template <int FMT>
+__device__ __forceinline__ void stage_tile(TileLDS &L, const ExtractArgs &a, int64_t T0, uint64_t *ctrs, int tid, uint64_t tile_first_read,
+                                           bool active) {
+  TileRaw R;
+  tile_prefetch<FMT>(R, a, T0, tid, tile_first_read, active);
+  tile_encode<FMT>(L, R, a, T0, ctrs, tid, active);
 }
 
 // Cut the k-mer that starts at local position lp out of the staged tile.  Returns false if the

@@ -132,7 +132,11 @@ def main():
     ap_tuning = dict(mode=1) if a.table_path else ({k: int(v) for k, v in (kv.split("=") for kv in a.tune.split(","))} if a.tune else None)
     kc = pkg.KmerCounter(k, device=local_rank, rank_me=rank, rank_n=world, max_elems=est_unique, time_kernels=True,
                          max_kmers_buffered=int(nreads * (L - k - 1) * 1.02) + (1 << 20), tuning=ap_tuning)
-    kc.set_stream(torch.cuda.current_stream().cuda_stream)
+    # one explicit stream for everything (torch ops, RCCL enqueue order, the library's kernels): torch's default
+    # stream is the null handle, which the library would read as "use your own stream"
+    stream = torch.cuda.Stream(device=dev)
+    torch.cuda.set_stream(stream)
+    kc.set_stream(stream.cuda_stream)
     kc.synth_reads_device(d_bases, d_quals, d_offs, nreads, first_read=rank * nreads, params=params)
     torch.cuda.synchronize()
 

@@ -649,31 +649,27 @@ static int bk_drain_to_table(kc_ctx *c) {
 static bool bk_active(const kc_ctx *c) { return c->tuning.mode == 0 && !c->table_mode; }
 
 // ---- extraction launches -----------------------------------------------------------------------
-template <int NL, int MODE, int FMT>
+template <int NL, int FMT>
 static void launch_extract_t(kc_ctx *c, const ExtractArgs &a, unsigned ntiles) {
-  hipLaunchKernelGGL((kc_extract_kernel<NL, MODE, FMT>), dim3(ntiles), dim3(TPB), 0, c->stream, a, c->table, c->d_ctrs);
+  hipLaunchKernelGGL((kc_extract_kernel<NL, FMT>), dim3(ntiles), dim3(TPB), 0, c->stream, a, c->table, c->d_ctrs);
 }
 
-template <int MODE, int FMT>
+template <int FMT>
 static void launch_extract_m(kc_ctx *c, const ExtractArgs &a, unsigned ntiles) {
   switch (c->nl) {
-    case 1: launch_extract_t<1, MODE, FMT>(c, a, ntiles); break;
-    case 2: launch_extract_t<2, MODE, FMT>(c, a, ntiles); break;
-    case 3: launch_extract_t<3, MODE, FMT>(c, a, ntiles); break;
-    default: launch_extract_t<4, MODE, FMT>(c, a, ntiles); break;
+    case 1: launch_extract_t<1, FMT>(c, a, ntiles); break;
+    case 2: launch_extract_t<2, FMT>(c, a, ntiles); break;
+    case 3: launch_extract_t<3, FMT>(c, a, ntiles); break;
+    default: launch_extract_t<4, FMT>(c, a, ntiles); break;
   }
 }
 
-static void launch_extract(kc_ctx *c, const ExtractArgs &a, unsigned ntiles, int mode, int fmt) {
-  KernelTimer kt(c, mode == MODE_INSERT ? KT_EXTRACT_INSERT : KT_EXTRACT_BIN);
-  if (mode == MODE_INSERT) {
-    if (fmt == FMT_READS) launch_extract_m<MODE_INSERT, FMT_READS>(c, a, ntiles);
-    else if (fmt == FMT_PACKED) launch_extract_m<MODE_INSERT, FMT_PACKED>(c, a, ntiles);
-    else launch_extract_m<MODE_INSERT, FMT_SEQBLOCK>(c, a, ntiles);
-  } else {
-    if (fmt == FMT_READS) launch_extract_m<MODE_BIN, FMT_READS>(c, a, ntiles);
-    else launch_extract_m<MODE_BIN, FMT_SEQBLOCK>(c, a, ntiles);
-  }
+// global-table path: extract and insert in one kernel
+static void launch_extract(kc_ctx *c, const ExtractArgs &a, unsigned ntiles, int fmt) {
+  KernelTimer kt(c, KT_EXTRACT_INSERT);
+  if (fmt == FMT_READS) launch_extract_m<FMT_READS>(c, a, ntiles);
+  else if (fmt == FMT_PACKED) launch_extract_m<FMT_PACKED>(c, a, ntiles);
+  else launch_extract_m<FMT_SEQBLOCK>(c, a, ntiles);
 }
 
 // One block of device-resident input through extraction, in chunks of tiles.  mode MODE_INSERT feeds this
@@ -752,7 +748,7 @@ static int run_extract_device(kc_ctx *c, const uint8_t *bases, const uint8_t *qu
       int rc = launch_bin_reads(c, a, nt, fmt);
       if (rc) return rc;
     } else {
-      launch_extract(c, a, (unsigned)nt, mode, fmt);
+      launch_extract(c, a, (unsigned)nt, fmt);
     }
     HIPCHK(hipGetLastError());
     t0 += nt;

@@ -1,7 +1,8 @@
 // kc_kernels.hpp -- gfx950 kernels of libkcount_mi355 (wave64, no MFMA: integer / hash work).
 //
-//   kc_extract_kernel      reads -> canonical k-mer records (+ packed extension codes), then either
-//                          inserts them into this shard's table or bins them by owner shard.
+//   kc_extract_kernel      reads -> canonical k-mer records (+ packed extension codes), inserted into this
+//                          shard's global table (the bucketed path and the sender-side binning share its tile
+//                          staging and k-mer cutting: kc_bucketed.hpp).
 //                          Replaces parse_and_pack / build_supermers / pack_seqs and
 //                          gpu_unpack_supermer_block / get_kmer_from_supermer of the reference
 //                          (src/kcount/kcount-gpu/parse_and_pack.cpp:127-237,
@@ -354,7 +355,7 @@ __device__ __forceinline__ bool tile_kmer(const TileLDS &L, int lp, int k, uint6
   return true;
 }
 
-template <int NL, int MODE, int FMT>
+template <int NL, int FMT>
 __global__ __launch_bounds__(TPB) void kc_extract_kernel(ExtractArgs a, Table t, uint64_t *ctrs) {
   __shared__ TileLDS L;
   const int64_t T0 = (int64_t)(a.tile0 + blockIdx.x) * TILE;
@@ -369,40 +370,14 @@ __global__ __launch_bounds__(TPB) void kc_extract_kernel(ExtractArgs a, Table t,
     bool valid = (x > lo) && (x + a.k < hi) && tile_kmer<NL>(L, PRE + off, a.k, rec, h);
     uint32_t owner = 0;
     if (valid && a.rank_n > 1) owner = kc_owner_of_hash(h, a.rank_n);
-    if (MODE == MODE_INSERT) {
-      if (valid && owner == a.rank_me) {
-        table_insert<NL>(t, rec, ctrs);
-        n_ins++;
-      }
-    } else {
-      // bin by owner shard: one cursor bump per wave and shard present
-      for (uint32_t d = 0; d < a.rank_n; d++) {
-        const bool mine = valid && owner == d;
-        const uint64_t m = __ballot(mine);
-        if (!m) continue;
-        const uint32_t cnt = (uint32_t)__popcll(m);
-        uint64_t base = 0;
-        if (lane_id() == (uint32_t)__ffsll((long long)m) - 1)
-          base = atomicAdd((unsigned long long *)&ctrs[CTR_BIN0 + d], (unsigned long long)cnt);
-        base = __shfl(base, __ffsll((long long)m) - 1);
-        if (mine) {
-          const uint64_t idx = base + (uint64_t)__popcll(m & ((1ULL << lane_id()) - 1ULL));
-          if (idx < a.seg_capacity) {
-            uint64_t *dst = a.records + ((uint64_t)d * a.seg_capacity + idx) * NL;
-#pragma unroll
-            for (int j = 0; j < NL; j++) dst[j] = rec[j];
-          } else {
-            ctrs[CTR_OVERFLOW] = 1;
-          }
-        }
-      }
+    if (valid && owner == a.rank_me) {
+      table_insert<NL>(t, rec, ctrs);
+      n_ins++;
     }
   }
-  if (MODE == MODE_INSERT) {
-    // wave-reduce then one atomic
-    for (int o = 32; o > 0; o >>= 1) n_ins += __shfl_down(n_ins, o);
-    if (lane_id() == 0 && n_ins) atomicAdd((unsigned long long *)&ctrs[CTR_INSERTED], (unsigned long long)n_ins);
-  }
+  // wave-reduce then one atomic
+  for (int o = 32; o > 0; o >>= 1) n_ins += __shfl_down(n_ins, o);
+  if (lane_id() == 0 && n_ins) atomicAdd((unsigned long long *)&ctrs[CTR_INSERTED], (unsigned long long)n_ins);
 }
 
 template <int NL>

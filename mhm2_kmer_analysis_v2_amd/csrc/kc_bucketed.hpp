@@ -711,18 +711,21 @@ template <int NL>
 struct CountLDS {  // header at the start of the dynamic LDS; the arrays follow, strided by the region's S
   static constexpr uint32_t SMAX = NL <= 2 ? 4096 : 2048;
   uint32_t chain[CHAIN_LDS];  // the region's chunk ids
-  uint32_t nout, nent, fail, gbase_lo, gbase_hi;
+  uint32_t nout, nocc, fail, gbase_lo, gbase_hi;
   unsigned long long sum;
   static constexpr size_t header_bytes() { return (sizeof(CountLDS<NL>) + 15) & ~size_t(15); }
-  static constexpr size_t bytes(uint32_t S) { return header_bytes() + (size_t)S * (8 * NL + 20); }
+  static constexpr size_t bytes(uint32_t S) { return header_bytes() + (size_t)S * (8 * NL + 20 + 2); }
 };
 
 // the arrays of one region table: word w of slot s at keys[w*S + s] (the LAST word is the claim word);
 // ext[q*S + s]: q = 0 left A|C<<16, 1 left G|T<<16, 2 right A|C<<16, 3 right G|T<<16
+// occ lists the occupied slots in claim order, so that the vote, the write-out and the clean-up of a region visit
+// only its entries (dense lanes) instead of scanning every slot
 struct CountTab {
   uint64_t *keys;
   uint32_t *cnt;
   uint32_t *ext;
+  uint16_t *occ;
   uint32_t S;
 };
 
@@ -732,6 +735,7 @@ __device__ __forceinline__ CountTab count_tab(uint8_t *smem, uint32_t S) {
   t.keys = reinterpret_cast<uint64_t *>(smem + CountLDS<NL>::header_bytes());
   t.cnt = reinterpret_cast<uint32_t *>(t.keys + (size_t)NL * S);
   t.ext = t.cnt + S;
+  t.occ = reinterpret_cast<uint16_t *>(t.ext + 4 * (size_t)S);
   t.S = S;
   return t;
 }
@@ -753,8 +757,20 @@ struct OutBufs {
   uint64_t *cursor;  // global append position (results: &ctrs[CTR_OUT])
 };
 
+// append the slots that lanes have just claimed to the region's list: one LDS atomic per wave
+__device__ __forceinline__ void occ_push(uint32_t *nocc, uint16_t *occ, bool is_new, uint32_t slot) {
+  const uint64_t m = __ballot(is_new);
+  if (m) {
+    const int leader = __ffsll((long long)m) - 1;
+    uint32_t base = 0;
+    if ((int)lane_id() == leader) base = atomicAdd(nocc, (uint32_t)__popcll(m));
+    base = __shfl(base, leader);
+    if (is_new) occ[base + (uint32_t)__popcll(m & ((1ULL << lane_id()) - 1ULL))] = (uint16_t)slot;
+  }
+}
+
 template <int NL>
-__device__ __forceinline__ void lds_insert(CountLDS<NL> &T, const CountTab &tb, const uint64_t (&rec)[NL]) {
+__device__ __forceinline__ void lds_insert(CountLDS<NL> &T, const CountTab &tb, const uint64_t (&rec)[NL], bool valid) {
   const uint32_t SM = tb.S, S = tb.S;
   uint64_t key[NL];
 #pragma unroll
@@ -764,6 +780,8 @@ __device__ __forceinline__ void lds_insert(CountLDS<NL> &T, const CountTab &tb, 
   uint32_t s = hash_slot(kc_hash<NL>(key), S);
   unsigned long long *claim = (unsigned long long *)&tb.keys[(NL - 1) * SM];
   uint32_t probes = 0;
+  bool is_new = false;
+  if (valid)
   for (;;) {
     unsigned long long cur = __hip_atomic_load(&claim[s], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
     if (cur == KEY_EMPTY) {
@@ -775,7 +793,7 @@ __device__ __forceinline__ void lds_insert(CountLDS<NL> &T, const CountTab &tb, 
           __threadfence_block();
           atomicExch(&claim[s], (unsigned long long)key[NL - 1]);
         }
-        atomicAdd(&T.nent, 1u);
+        is_new = true;
         break;
       }
     }
@@ -791,12 +809,16 @@ __device__ __forceinline__ void lds_insert(CountLDS<NL> &T, const CountTab &tb, 
     s = (s + 1) & (S - 1u);
     if (++probes >= S) {  // every slot holds some other k-mer
       T.fail = 1;
-      return;
+      valid = false;
+      break;
     }
   }
-  atomicAdd(&tb.cnt[s], 1u);
-  if (le < 4u) ext_bump(tb.ext, SM, s, 0, le);
-  if (re < 4u) ext_bump(tb.ext, SM, s, 1, re);
+  (void)is_new;
+  if (valid) {
+    atomicAdd(&tb.cnt[s], 1u);
+    if (le < 4u) ext_bump(tb.ext, SM, s, 0, le);
+    if (re < 4u) ext_bump(tb.ext, SM, s, 1, re);
+  }
 }
 
 // One-word keys: the probe written for a low instruction count.  The region kernels are bound by instruction
@@ -854,22 +876,31 @@ __global__ __launch_bounds__(WGB) void kc_count_kernel(Geom gm, BucketBufs bb, O
 #else
 #define KC_STAMP(k)
 #endif
+  // the table is cleared once; every region leaves it clean again by resetting exactly the slots it claimed
+  for (uint32_t s = tid; s < S; s += WGB) {
+#pragma unroll
+    for (int w = 0; w < NL; w++) tb.keys[w * SM + s] = KEY_EMPTY;
+    tb.cnt[s] = 0;
+#pragma unroll
+    for (int e = 0; e < 4; e++) tb.ext[e * SM + s] = 0;
+  }
+  if (tid == 0) T.nocc = 0;
+  __syncthreads();
+  auto reset_slot = [&](uint32_t s) {
+#pragma unroll
+    for (int w = 0; w < NL; w++) tb.keys[w * SM + s] = KEY_EMPTY;
+    tb.cnt[s] = 0;
+#pragma unroll
+    for (int e = 0; e < 4; e++) tb.ext[e * SM + s] = 0;
+  };
   for (size_t r = blockIdx.x; r < R; r += gridDim.x) {
     const uint32_t n = bb.cnt2[r];
     if (n == 0 || bb.flag[r]) continue;  // uniform across the workgroup
 #ifdef KC_STAMPS
     if (stamp) tprev = __builtin_amdgcn_s_memtime();
 #endif
-    for (uint32_t s = tid; s < S; s += WGB) {
-#pragma unroll
-      for (int w = 0; w < NL; w++) tb.keys[w * SM + s] = KEY_EMPTY;
-      tb.cnt[s] = 0;
-#pragma unroll
-      for (int e = 0; e < 4; e++) tb.ext[e * SM + s] = 0;
-    }
     if (tid == 0) {
       T.nout = 0;
-      T.nent = 0;
       T.fail = 0;
       T.sum = 0;
     }
@@ -878,7 +909,7 @@ __global__ __launch_bounds__(WGB) void kc_count_kernel(Geom gm, BucketBufs bb, O
       if ((uint32_t)tid < nch) T.chain[tid] = bb.chain2[r * gm.L2MAX + tid];
     }
     __syncthreads();
-    KC_STAMP(0)  // zero + chain
+    KC_STAMP(0)  // chain
     // several independent loads in flight per thread before the dependent LDS work starts
 #ifndef KC_BATCH
 #define KC_BATCH 8
@@ -901,109 +932,108 @@ __global__ __launch_bounds__(WGB) void kc_count_kernel(Geom gm, BucketBufs bb, O
 #pragma unroll
         for (int w = 0; w < NL; w++) rec[j][w] = src[j][w];
       if constexpr (NL == 1) {
-        {
-          uint32_t failed = 0;
-#pragma unroll
-          for (int j = 0; j < BATCH; j++) {
-            const uint32_t v = (i0 + (uint32_t)j * WGB + tid) < n ? 1u : 0u;
-            const uint64_t r0 = rec[j][0], key = r0 & ~KC_EXT_MASK;
-            uint64_t kk[1] = {key};
-            const uint32_t s = lds_probe1((unsigned long long *)tb.keys, S - 1u, key, hash_slot(kc_hash<1>(kk), S), v, failed);
-            // S5/S6: the k-mer itself, and each extension that is an ACGT base (codes 0-3; 4 = none adds 0)
-            const uint32_t le = (uint32_t)r0 & 7u, re = ((uint32_t)r0 >> 3) & 7u;
-            atomicAdd(&tb.cnt[s], v);
-            atomicAdd(&tb.ext[((le >> 1) & 1u) * SM + s], (v << ((le & 1u) << 4)) & (((le >> 2) & 1u) - 1u));
-            atomicAdd(&tb.ext[(2u + ((re >> 1) & 1u)) * SM + s], (v << ((re & 1u) << 4)) & (((re >> 2) & 1u) - 1u));
-          }
-          if (failed) T.fail = 1;
-        }
-      } else {
+        uint32_t failed = 0;
 #pragma unroll
         for (int j = 0; j < BATCH; j++) {
-          const uint32_t i = i0 + (uint32_t)j * WGB + tid;
-          if (i < n) lds_insert<NL>(T, tb, rec[j]);
+          const uint32_t v = (i0 + (uint32_t)j * WGB + tid) < n ? 1u : 0u;
+          const uint64_t r0 = rec[j][0], key = r0 & ~KC_EXT_MASK;
+          uint64_t kk[1] = {key};
+          const uint32_t s = lds_probe1((unsigned long long *)tb.keys, S - 1u, key, hash_slot(kc_hash<1>(kk), S), v, failed);
+          // S5/S6: the k-mer itself, and each extension that is an ACGT base (codes 0-3; 4 = none adds 0)
+          const uint32_t le = (uint32_t)r0 & 7u, re = ((uint32_t)r0 >> 3) & 7u;
+          atomicAdd(&tb.cnt[s], v);
+          atomicAdd(&tb.ext[((le >> 1) & 1u) * SM + s], (v << ((le & 1u) << 4)) & (((le >> 2) & 1u) - 1u));
+          atomicAdd(&tb.ext[(2u + ((re >> 1) & 1u)) * SM + s], (v << ((re & 1u) << 4)) & (((re >> 2) & 1u) - 1u));
         }
+        if (failed) T.fail = 1;
+      } else {
+#pragma unroll
+        for (int j = 0; j < BATCH; j++) lds_insert<NL>(T, tb, rec[j], (i0 + (uint32_t)j * WGB + tid) < n);
       }
     }
     __syncthreads();
     KC_STAMP(1)  // loads + inserts + barrier
-    // a k-mer seen more than 65535 times may have overflowed a packed 16-bit extension counter
-    {
-      uint32_t ne = 0;
-      for (uint32_t s = tid; s < S; s += WGB) {
-        const uint32_t c = tb.cnt[s];
-        ne += c != 0;
-        if (c > KC_COUNT_MAX) T.fail = 1;
-      }
-      if (NL == 1) {  // one-word inserts do not count new entries one by one
-        for (int o = 32; o > 0; o >>= 1) ne += __shfl_down(ne, o);
-        if (lane_id() == 0 && ne) atomicAdd(&T.nent, ne);
-      }
+    // list the occupied slots (one pass over the table, one LDS atomic per wave): the vote, the write-out and the
+    // clean-up then visit only the region's entries, with every lane busy
+    for (uint32_t s0 = 0; s0 < S; s0 += WGB) {
+      const uint32_t s = s0 + tid;
+      occ_push(&T.nocc, tb.occ, s < S && tb.cnt[s] != 0u, s);
     }
     __syncthreads();
-    if (T.fail) {  // more distinct k-mers than slots, or a saturated k-mer: the whole region goes to the global table instead
-      if (tid == 0) bb.flag[r] = 2;
-      __syncthreads();
-      continue;
-    }
-    KC_STAMP(2)  // saturation scan
-    // S7 vote + S8 purge; survivors get a rank
-    for (uint32_t s = tid; s < S; s += WGB) {
+    KC_STAMP(2)  // list the entries
+    const uint32_t nocc = T.nocc;
+    // S7 vote + S8 purge over the region's entries; survivors get a rank.  A k-mer seen more than 65535 times may
+    // have overflowed a packed 16-bit extension counter: the region then goes to the global table instead.
+    for (uint32_t e = tid; e < nocc; e += WGB) {
+      const uint32_t s = tb.occ[e];
       uint32_t packed = ~0u;
-      if (tb.keys[(NL - 1) * SM + s] != KEY_EMPTY) {
-        const uint32_t count = tb.cnt[s];  // <= 65535 here: regions with a larger count were flagged above
-        if (DUMP) {
-          packed = count | (atomicAdd(&T.nout, 1u) << 20);
-        } else if (count >= 2) {
-          uint32_t lc[4], rc[4];
+      const uint32_t count = tb.cnt[s];
+      if (count > KC_COUNT_MAX) T.fail = 1;
+      if (DUMP) {
+        packed = count | (atomicAdd(&T.nout, 1u) << 20);
+      } else if (count >= 2) {
+        uint32_t lc[4], rc[4];
 #pragma unroll
-          for (int e = 0; e < 4; e++) {
-            lc[e] = ext_get(tb.ext, SM, s, 0, e);
-            rc[e] = ext_get(tb.ext, SM, s, 1, e);
-          }
-          const uint32_t l = vote_ext(lc, count, dmin_thres), rr = vote_ext(rc, count, dmin_thres);
-          if (l < 4u && rr < 4u) {
-            const uint32_t rank = atomicAdd(&T.nout, 1u);
-            packed = count | (l << 16) | (rr << 18) | (rank << 20);
-            atomicAdd(&T.sum, (unsigned long long)count);
-          }
+        for (int x = 0; x < 4; x++) {
+          lc[x] = ext_get(tb.ext, SM, s, 0, x);
+          rc[x] = ext_get(tb.ext, SM, s, 1, x);
+        }
+        const uint32_t l = vote_ext(lc, count, dmin_thres), rr = vote_ext(rc, count, dmin_thres);
+        if (l < 4u && rr < 4u) {
+          const uint32_t rank = atomicAdd(&T.nout, 1u);
+          packed = (count & 0xFFFFu) | (l << 16) | (rr << 18) | (rank << 20);
+          atomicAdd(&T.sum, (unsigned long long)count);
         }
       }
       tb.cnt[s] = packed;
     }
     __syncthreads();
+    if (T.fail) {  // more distinct k-mers than slots, or a saturated k-mer: the whole region goes to the global table instead
+      for (uint32_t e = tid; e < nocc; e += WGB) reset_slot(tb.occ[e]);
+      __syncthreads();
+      if (tid == 0) {
+        bb.flag[r] = 2;
+        T.nocc = 0;
+      }
+      __syncthreads();
+      continue;
+    }
     if (tid == 0) {
       const uint64_t gb = atomicAdd((unsigned long long *)out.cursor, (unsigned long long)T.nout);
       T.gbase_lo = (uint32_t)gb;
       T.gbase_hi = (uint32_t)(gb >> 32);
       if (!DUMP) {
-        atomicAdd((unsigned long long *)&cb[CB_ENTRIES], (unsigned long long)T.nent);
-        atomicAdd((unsigned long long *)&ctrs[CTR_PURGED], (unsigned long long)(T.nent - T.nout));
+        atomicAdd((unsigned long long *)&cb[CB_ENTRIES], (unsigned long long)nocc);
+        atomicAdd((unsigned long long *)&ctrs[CTR_PURGED], (unsigned long long)(nocc - T.nout));
         atomicAdd((unsigned long long *)&ctrs[CTR_SUM_COUNTS], T.sum);
       }
+      T.nocc = 0;  // every thread has its copy; the next region starts an empty list
     }
     __syncthreads();
     KC_STAMP(3)  // vote + reserve
     const uint64_t gbase = ((uint64_t)T.gbase_hi << 32) | T.gbase_lo;
-    for (uint32_t s = tid; s < S; s += WGB) {
+    for (uint32_t e = tid; e < nocc; e += WGB) {
+      const uint32_t s = tb.occ[e];
       const uint32_t p = tb.cnt[s];
-      if (p == ~0u) continue;
-      const uint64_t o = gbase + (p >> 20);
-      if (o < out.cap) {  // beyond the arrays: the host sees the cursor past cap and re-runs with more room
+      if (p != ~0u) {
+        const uint64_t o = gbase + (p >> 20);
+        if (o < out.cap) {  // beyond the arrays: the host sees the cursor past cap and re-runs with more room
 #pragma unroll
-        for (int w = 0; w < NL; w++) out.keys[o * NL + w] = tb.keys[w * SM + s];
-        out.counts[o] = (uint16_t)(p & 0xFFFFu);
-        if (DUMP) {
+          for (int w = 0; w < NL; w++) out.keys[o * NL + w] = tb.keys[w * SM + s];
+          out.counts[o] = (uint16_t)(p & 0xFFFFu);
+          if (DUMP) {
 #pragma unroll
-          for (int e = 0; e < 8; e++) out.exts[o * 8 + e] = (uint16_t)ext_get(tb.ext, SM, s, e >> 2, e & 3);
-        } else {
-          out.left[o] = (uint8_t)("ACGT"[(p >> 16) & 3u]);
-          out.right[o] = (uint8_t)("ACGT"[(p >> 18) & 3u]);
+            for (int x = 0; x < 8; x++) out.exts[o * 8 + x] = (uint16_t)ext_get(tb.ext, SM, s, x >> 2, x & 3);
+          } else {
+            out.left[o] = (uint8_t)("ACGT"[(p >> 16) & 3u]);
+            out.right[o] = (uint8_t)("ACGT"[(p >> 18) & 3u]);
+          }
         }
       }
+      reset_slot(s);  // leave the table clean for the next region
     }
     __syncthreads();
-    KC_STAMP(4)  // write out
+    KC_STAMP(4)  // write out + clean
   }
 #ifdef KC_STAMPS
   if (stamp)

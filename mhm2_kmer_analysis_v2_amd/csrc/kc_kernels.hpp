@@ -171,6 +171,10 @@ __device__ __forceinline__ bool in_bitmap(uint32_t c, uint32_t bm) { return ((c 
 // the registers into the LDS image.  Aligned coordinate x = byte index from the 16-byte aligned base address;
 // local position lp = x - (T0 - PRE).  Thread tid (0..TPB-1 of the TPB threads sharing the tile) owns the
 // 16-byte groups tid and tid + TPB.
+// Barrier for data exchanged through LDS only: __syncthreads() would also drain the vector-memory counter, i.e.
+// wait for every global store and prefetch load this wave still has in flight.
+__device__ __forceinline__ void tile_barrier() { asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory"); }
+
 constexpr int GROUPS_PER_THREAD = (NGROUP + TPB - 1) / TPB;  // 2
 
 struct TileRaw {
@@ -220,9 +224,9 @@ __device__ __forceinline__ void tile_encode(TileLDS &L, const TileRaw &R, const 
                                             bool active) {
   // every thread of the workgroup reaches both barriers
   for (int i = tid; i < NWORD + 1; i += TPB) L.gap[i] = 0;
-  __syncthreads();
+  tile_barrier();
   if (!active) {
-    __syncthreads();
+    tile_barrier();
     return;
   }
   const int64_t lo = a.align, hi = (int64_t)a.align + (int64_t)a.total;
@@ -294,7 +298,7 @@ __device__ __forceinline__ void tile_encode(TileLDS &L, const TileRaw &R, const 
     }
   }
   if (bad) ctrs[CTR_BAD_BASE] = 1;
-  __syncthreads();
+  tile_barrier();
 }
 
 // both halves back to back (kernels that do not pipeline their tiles)

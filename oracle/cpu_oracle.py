@@ -18,6 +18,8 @@ u16p = C.POINTER(C.c_uint16)
 
 
 def build(force=False):
+    if os.environ.get("ORC_LIB"):  # e.g. the sanitizer build: make -C oracle liborc_asan.so
+        return os.environ["ORC_LIB"]
     so = os.path.join(_HERE, "liborc.so")
     src = os.path.join(_HERE, "kcount_oracle.c")
     if force or not os.path.exists(so) or os.path.getmtime(so) < os.path.getmtime(src):

@@ -196,7 +196,7 @@ int kc_get_stats(kc_ctx *ctx, kc_stats *out);
 typedef struct kc_tuning {
   uint32_t mode;          /* 0 auto (bucketed), 1 global-table path only */
   uint32_t writers;       /* level-1 writer workgroups (<= 512) */
-  uint32_t p1, p2;        /* fan-out of level 1 / level 2: powers of two <= 1024 */
+  uint32_t p1, p2;        /* fan-out of level 1 / level 2: 1..1024 each */
   uint32_t slots;         /* LDS slots per region */
   uint32_t chunk1, chunk2;         /* records per chunk of the level-1 / level-2 chains: powers of two */
   uint32_t chain1_max, chain2_max; /* longest chain, in chunks, of a (writer,bucket) segment / a region */

@@ -436,19 +436,20 @@ static int bk_init(kc_ctx *c) {
   const uint64_t bcap = c->cfg.max_kmers_buffered ? c->cfg.max_kmers_buffered : (1ULL << 26);
   const double est = c->cfg.max_elems ? (double)c->cfg.max_elems : 0.35 * (double)bcap;  // 1/depth(4) + error share, kmer_dht.cpp:126-131
   const uint32_t smax = count_smax(c->nl);
-  // LDS tables are meant to run below ~0.55 load.  Half-size tables let two region workgroups share a CU (one's
-  // barriers and scans overlap the other's inserts: measured 10 % faster counting), so prefer them while the
-  // 2^20 regions of the two split levels still cover the expected number of distinct k-mers.
+  // Region tables are meant to run at about 0.6 load: fewer, fuller regions amortise the per-region costs (barriers,
+  // the exposed latency of the first loads and of the output reservation) better than more, emptier ones.
+  // Half-size tables let two region workgroups share a CU (one's barriers and scans overlap the other's inserts:
+  // measured 10 % faster counting), so prefer them while 2^20 regions still cover the expected distinct k-mers.
   g.S = t.slots ? std::min(std::max(t.slots, 16u), smax) : smax;
   while (g.S & (g.S - 1)) g.S &= g.S - 1;  // power of two (round down)
-  if (!t.slots && est / (0.55 * (g.S / 2)) + 1 <= (double)(1u << 20)) g.S /= 2;
-  const uint64_t regions_needed = (uint64_t)(est / (0.55 * g.S)) + 1;
-  const uint32_t bits = std::min<uint32_t>(ilog2(regions_needed), 20);
-  g.log2P1 = t.p1 ? ilog2(t.p1) : bits / 2;  // level 1 holds fewer records per round than level 2: give it the smaller fan-out
-  g.log2P2 = t.p2 ? ilog2(t.p2) : (bits + 1) / 2;
-  if (g.log2P1 > 10 || g.log2P2 > 10) return KC_ERR_INVALID_ARG;
-  g.P1 = 1u << g.log2P1;
-  g.P2 = 1u << g.log2P2;
+  const double target_load = 0.6;
+  if (!t.slots && est / (target_load * (g.S / 2)) + 1 <= (double)(1u << 20)) g.S /= 2;
+  const uint64_t regions_needed = std::min<uint64_t>((uint64_t)(est / (target_load * g.S)) + 1, 1ULL << 20);
+  // the two fan-outs multiply to the number of regions; any value up to 1024 each (the hash fields are mapped by
+  // multiply-shift), level 1 the smaller one because it holds fewer records per round
+  g.P1 = t.p1 ? t.p1 : (uint32_t)std::max<double>(1.0, floor(sqrt((double)regions_needed)));
+  g.P2 = t.p2 ? t.p2 : (uint32_t)((regions_needed + g.P1 - 1) / g.P1);
+  if (g.P1 < 1 || g.P2 < 1 || g.P1 > PMAX || g.P2 > PMAX) return KC_ERR_INVALID_ARG;
   // one writer per CU, but never so many that a writer's share of the buffer is below a few rounds of records
   g.G = t.writers ? std::min<uint32_t>(t.writers, GMAX)
                   : (uint32_t)std::max<uint64_t>(1, std::min<uint64_t>((uint64_t)std::min<int>(c->num_cus, GMAX), bcap / (4 * 16384)));
@@ -1391,8 +1392,7 @@ extern "C" int kc_set_tuning(kc_ctx *c, const kc_tuning *t) {
   if (c->started) return KC_ERR_STATE;
   if (t->mode > 1) return KC_ERR_INVALID_ARG;
   auto pow2_or_zero = [](uint32_t v) { return (v & (v - 1)) == 0; };
-  if (!pow2_or_zero(t->p1) || !pow2_or_zero(t->p2) || !pow2_or_zero(t->chunk1) || !pow2_or_zero(t->chunk2) || t->p1 > PMAX ||
-      t->p2 > PMAX || t->writers > GMAX)
+  if (!pow2_or_zero(t->chunk1) || !pow2_or_zero(t->chunk2) || t->p1 > PMAX || t->p2 > PMAX || t->writers > GMAX)
     return KC_ERR_INVALID_ARG;
   if (memcmp(&c->tuning, t, sizeof(*t)) == 0) return KC_OK;  // unchanged: keep the arenas
   HIPCHK(hipSetDevice(c->cfg.device));

@@ -46,8 +46,7 @@ template <int NL> struct Rnd {
 // from (a level-1 writer; a level-2 bucket), so appends need no global atomics and a destination that
 // grows far beyond the mean (k-mer counts are heavy-tailed) costs no memory up front.
 struct Geom {
-  uint32_t G, P1, P2, S;       // writers, fan-outs (powers of two), LDS slots per region
-  uint32_t log2P1, log2P2;
+  uint32_t G, P1, P2, S;       // writers, fan-outs (any value up to PMAX), LDS slots per region (power of two)
   uint32_t log2CH1, log2CH2;   // records per chunk (powers of two)
   uint32_t L1MAX, L2MAX;       // longest chain of a (writer,bucket) segment / of a region, in chunks
   uint32_t A1;                 // chunks in each writer's arena
@@ -73,10 +72,14 @@ enum {  // counters of this path, one u64 each
   CB_OVF1 = 0, CB_OVF2, CB_FATAL, CB_FLAGGED_RECS, CB_DUMP, CB_ENTRIES, CB_COUNT = 16
 };
 
-__device__ __forceinline__ uint32_t hash_b1(uint64_t h, const Geom &g) { return (uint32_t)h & (g.P1 - 1); }
-__device__ __forceinline__ uint32_t hash_b2(uint64_t h, const Geom &g) { return (uint32_t)(h >> g.log2P1) & (g.P2 - 1); }
-__device__ __forceinline__ uint32_t hash_slot(uint64_t h, uint32_t S) {  // S is a power of two
-  return (uint32_t)(h >> 21) & (S - 1u);
+// Four independent fields of the 64-bit k-mer hash: bits 0-15 pick the level-1 bucket, 16-31 the level-2 bucket
+// (each by multiply-shift, so the fan-outs need not be powers of two; 65536 / P >= 64 values per bucket keeps the
+// imbalance under 1.6 %), bits 32-47 the slot inside the region table, and the top bits the owner shard
+// (kc_owner_of_hash weighs bits 32-63 towards the top).
+__device__ __forceinline__ uint32_t hash_b1(uint64_t h, const Geom &g) { return (((uint32_t)h & 0xFFFFu) * g.P1) >> 16; }
+__device__ __forceinline__ uint32_t hash_b2(uint64_t h, const Geom &g) { return ((((uint32_t)h >> 16) & 0xFFFFu) * g.P2) >> 16; }
+__device__ __forceinline__ uint32_t hash_slot(uint64_t h, uint32_t S) {  // S is a power of two <= 4096
+  return (uint32_t)(h >> 32) & (S - 1u);
 }
 
 template <int NL>

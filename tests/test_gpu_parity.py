@@ -35,6 +35,7 @@ def arrays(reads, quals):
 PATHS = {
     "bucketed": None,
     "bucketed-small": dict(writers=3, p1=4, p2=8, slots=512),
+    "bucketed-odd": dict(writers=5, p1=7, p2=13, slots=256),
     "table": dict(mode=1),
 }
 

@@ -856,8 +856,9 @@ __device__ __forceinline__ uint32_t lds_probe1(unsigned long long *claim, uint32
 
 // DUMP = false: S7 vote + S8 purge, survivors to the result arrays.  DUMP = true: every entry with its raw
 // (clipped) counters, for tests of S5/S6; no statistics are touched.
+// __launch_bounds__(WGB, 8): two 1024-thread workgroups per CU need at most 64 registers per lane.
 template <int NL, bool DUMP>
-__global__ __launch_bounds__(WGB) void kc_count_kernel(Geom gm, BucketBufs bb, OutBufs out, int dmin_thres, uint64_t *ctrs,
+__global__ __launch_bounds__(WGB, 8) void kc_count_kernel(Geom gm, BucketBufs bb, OutBufs out, int dmin_thres, uint64_t *ctrs,
                                                        uint64_t *cb) {
   extern __shared__ __align__(16) uint8_t smem[];
   CountLDS<NL> &T = *reinterpret_cast<CountLDS<NL> *>(smem);

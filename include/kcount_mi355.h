@@ -68,6 +68,9 @@ typedef struct kc_config {
 } kc_config;
 
 #define KC_FLAG_NONE 0u
+#define KC_FLAG_REFERENCE_OWNER 2u /* owner shard = the reference's KmerDHT::get_kmer_target_rank (quick_hash of the minimizer,
+                                     src/kcount/kmer_dht.cpp:117-119,192-196) instead of the k-mer hash: for runs mixed with
+                                     unmodified MHM2 ranks; slower (k-m+1 m-mer comparisons per k-mer) */
 #define KC_FLAG_TIME_KERNELS 1u /* bracket every kernel launch with HIP events on its own stream (kc_get_kernel_times) */
 
 /* Scalars the reference logs (src/kcount/kcount.cpp:94-102,158-160;
@@ -115,6 +118,10 @@ int kc_num_longs(int kmer_len);
  * src/kcount/kmer_dht.cpp:192-196; any deterministic function of the k-mer
  * gives the same final set).  Host-callable. */
 int kc_owner(const uint64_t *kmer_words, int kmer_len, int rank_n);
+/* The reference's own target rank, bit for bit: quick_hash(minimizer(kmer, m)) % rank_n with m = clamp(2k/3+1, 15, 27)
+ * (src/kmer.cpp:349-398,459-468, src/hash_funcs.c:332-342, src/kcount/kmer_dht.cpp:117-119,192-196).  Host-callable;
+ * contexts created with KC_FLAG_REFERENCE_OWNER use it on the device. */
+int kc_owner_reference(const uint64_t *kmer_words, int kmer_len, int rank_n);
 
 /* ---- context ------------------------------------------------------------ */
 /* HashTableGPUDriver::init + ParseAndPackGPUDriver ctor (gpu_hash_table.cpp:522-624, parse_and_pack.cpp:239-267). */

@@ -9,6 +9,7 @@ KC_OK = 0
 KC_ERR_CAPACITY = -6
 KC_ERR_BAD_BASE = -7
 KC_FLAG_TIME_KERNELS = 1
+KC_FLAG_REFERENCE_OWNER = 2
 
 
 class KcError(RuntimeError):
@@ -61,6 +62,7 @@ SYMBOLS = {
     "kc_device_count": (C.c_int, []),
     "kc_num_longs": (C.c_int, [C.c_int]),
     "kc_owner": (C.c_int, [C.c_void_p, C.c_int, C.c_int]),
+    "kc_owner_reference": (C.c_int, [C.c_void_p, C.c_int, C.c_int]),
     "kc_create": (C.c_void_p, [C.POINTER(kc_config), C.POINTER(C.c_int)]),
     "kc_destroy": (None, [C.c_void_p]),
     "kc_set_stream": (C.c_int, [C.c_void_p, C.c_void_p]),

@@ -266,6 +266,16 @@ extern "C" int kc_owner(const uint64_t *w, int k, int rank_n) {
   return (int)kc_owner_of_hash(h, (uint32_t)rank_n);
 }
 
+extern "C" int kc_owner_reference(const uint64_t *w, int k, int rank_n) {
+  if (!w || check_k(k) || rank_n < 1) return KC_ERR_INVALID_ARG;
+  switch (kc_num_longs(k)) {
+    case 1: { uint64_t a[1] = {w[0]}, r[1]; kc_revcomp<1>(a, k, r); return (int)::kc_reference_owner<1>(a, r, k, (uint32_t)rank_n); }
+    case 2: { uint64_t a[2] = {w[0], w[1]}, r[2]; kc_revcomp<2>(a, k, r); return (int)::kc_reference_owner<2>(a, r, k, (uint32_t)rank_n); }
+    case 3: { uint64_t a[3] = {w[0], w[1], w[2]}, r[3]; kc_revcomp<3>(a, k, r); return (int)::kc_reference_owner<3>(a, r, k, (uint32_t)rank_n); }
+    default: { uint64_t a[4] = {w[0], w[1], w[2], w[3]}, r[4]; kc_revcomp<4>(a, k, r); return (int)::kc_reference_owner<4>(a, r, k, (uint32_t)rank_n); }
+  }
+}
+
 // ---- context -----------------------------------------------------------------------------------
 static int create_impl(kc_ctx *c) {
   HIPCHK(hipSetDevice(c->cfg.device));
@@ -694,6 +704,7 @@ static int run_extract_device(kc_ctx *c, const uint8_t *bases, const uint8_t *qu
   a.qual_cut = c->cfg.qual_offset + KC_QUAL_CUTOFF;
   a.rank_me = (uint32_t)c->cfg.rank_me;
   a.rank_n = (uint32_t)c->cfg.rank_n;
+  a.reference_owner = (c->cfg.flags & KC_FLAG_REFERENCE_OWNER) ? 1u : 0u;
   a.records = d_records;
   a.seg_capacity = seg_capacity;
   const uint64_t ntiles_total = (a.align + total + TILE - 1) / TILE;

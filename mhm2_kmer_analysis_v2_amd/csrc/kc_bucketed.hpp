@@ -371,8 +371,10 @@ __global__ __launch_bounds__(WGB) void kc_l1_reads_kernel(ExtractArgs a, Geom gm
         const int off = (round * RPOS + j) * TPB + qt;
         const int64_t x = T0 + off;
         uint64_t h = 0;
-        bool valid = active && (x > lo) && (x + a.k < hi) && tile_kmer<NL>(L.tile[q], PRE + off, a.k, rec[j], h);
-        if (valid && a.rank_n > 1) valid = kc_owner_of_hash(h, a.rank_n) == a.rank_me;
+        uint32_t owner = 0;
+        bool valid = active && (x > lo) && (x + a.k < hi) &&
+                     tile_kmer<NL>(L.tile[q], PRE + off, a.k, rec[j], h, a.rank_n, a.reference_owner, &owner);
+        if (valid && a.rank_n > 1) valid = owner == a.rank_me;
         br[j] = ~0u;
         if (valid) {
           const uint32_t b = hash_b1(h, gm);
@@ -433,7 +435,7 @@ __device__ __forceinline__ void split_round_flat(SplitLDS &L, uint64_t *sorted, 
     uint64_t r[NL];
 #pragma unroll
     for (int w = 0; w < NL; w++) r[w] = sorted[(size_t)i * NL + w];
-    const uint32_t b = bucket_of(rec_hash<NL>(r));
+    const uint32_t b = bucket_of(r);
     const uint32_t j = i - L.offs[b];
     if (j < H[b]) {
       const uint64_t base = ((uint64_t)L.c0[b] << 32) | L.dbase[b];
@@ -488,17 +490,29 @@ __global__ __launch_bounds__(WGB) void kc_bin_reads_kernel(ExtractArgs a, uint64
         const int off = (round * RPOS + j) * TPB + qt;
         const int64_t x = T0 + off;
         uint64_t h = 0;
-        const bool valid = active && (x > lo) && (x + a.k < hi) && tile_kmer<NL>(L.tile[q], PRE + off, a.k, rec[j], h);
+        uint32_t owner = 0;
+        const bool valid = active && (x > lo) && (x + a.k < hi) &&
+                           tile_kmer<NL>(L.tile[q], PRE + off, a.k, rec[j], h, P, a.reference_owner, &owner);
         br[j] = ~0u;
         if (valid) {
-          const uint32_t b = kc_owner_of_hash(h, P);
+          const uint32_t b = P > 1 ? owner : 0u;
           const uint32_t rank = atomicAdd(&L.sp.hist[buf][b], 1u);
           br[j] = b | (rank << 10);
         }
       }
       lds_barrier();
       split_round_flat<NL, RPOS>(L.sp, sorted, buf, P, rec, br, a.records, a.seg_capacity, ctrs + CTR_BIN0, ctrs + CTR_OVERFLOW,
-                                 [&](uint64_t h) { return kc_owner_of_hash(h, P); });
+                                 [&](const uint64_t (&r)[NL]) -> uint32_t {
+                                   if (P <= 1) return 0u;
+                                   uint64_t key[NL];
+#pragma unroll
+                                   for (int w = 0; w < NL; w++) key[w] = r[w];
+                                   key[NL - 1] &= ~KC_EXT_MASK;
+                                   if (!a.reference_owner) return kc_owner_of_hash(kc_hash<NL>(key), P);
+                                   uint64_t rc[NL];
+                                   kc_revcomp<NL>(key, a.k, rc);
+                                   return kc_reference_owner<NL>(key, rc, a.k, P);
+                                 });
       buf ^= 1;
     }
   }

@@ -121,6 +121,57 @@ KC_HD uint32_t kc_owner_of_hash(uint64_t h, uint32_t rank_n) {
   return (uint32_t)(((h >> 32) * (uint64_t)rank_n) >> 32);
 }
 
+// ---- the reference's own partition function (for runs mixed with unmodified MHM2 ranks) -----------------------
+// target rank = quick_hash(minimizer(kmer, m)) % rank_n, the minimizer being the GREATEST over the k-m+1 positions of
+// the LEAST of the forward m-mer and the reverse-complement m-mer at the mirrored position
+// (src/kmer.cpp:349-398,459-468; src/hash_funcs.c:332-342; src/kcount/kmer_dht.cpp:117-119,192-196).
+KC_HD uint64_t kc_quick_hash(uint64_t v) {
+  v = v * 3935559000370003845ULL + 2691343689449507681ULL;
+  v ^= v >> 21;
+  v ^= v << 37;
+  v ^= v >> 4;
+  v *= 4768777513237032717ULL;
+  v ^= v << 20;
+  v ^= v >> 41;
+  v ^= v << 5;
+  return v;
+}
+
+KC_HD int kc_minimizer_len(int k) {
+  int m = k * 2 / 3 + 1;
+  if (m < 15) m = 15;
+  if (m > 27) m = 27;
+  return m < k ? m : k;
+}
+
+// the m-mer starting at base i of a packed k-mer, MSB-aligned and masked to m bases (word picked by compile-time
+// indices only: a run-time array index would go to scratch memory on the device)
+template <int NL>
+KC_HD uint64_t kc_mmer_at(const uint64_t (&w)[NL], int i, int m) {
+  const int l = i >> 5, sh = 2 * (i & 31);
+  uint64_t hi = 0, lo = 0;
+#pragma unroll
+  for (int j = 0; j < NL; j++) {
+    if (j == l) hi = w[j];
+    if (j == l + 1) lo = w[j];
+  }
+  const uint64_t t = sh ? ((hi << sh) | (lo >> (64 - sh))) : hi;
+  return t & (~0ULL << (64 - 2 * m));
+}
+
+// f = a k-mer, r = its reverse complement (either order: the minimizer is the same for both strands)
+template <int NL>
+KC_HD uint32_t kc_reference_owner(const uint64_t (&f)[NL], const uint64_t (&r)[NL], int k, uint32_t rank_n) {
+  const int m = kc_minimizer_len(k), ncand = k - m + 1;
+  uint64_t best = 0;
+  for (int i = 0; i < ncand; i++) {
+    const uint64_t a = kc_mmer_at<NL>(f, i, m), b = kc_mmer_at<NL>(r, ncand - 1 - i, m);
+    const uint64_t least = a < b ? a : b;
+    if (least > best) best = least;
+  }
+  return (uint32_t)(kc_quick_hash(best) % (uint64_t)rank_n);
+}
+
 // ---- synthetic read stream ---------------------------------
 #define KC_SYNTH_MAX_GENOMES 1024
 

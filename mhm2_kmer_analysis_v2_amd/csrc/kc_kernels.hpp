@@ -72,6 +72,7 @@ struct ExtractArgs {
   int k;
   int qual_cut;             // qual_offset + KC_QUAL_CUTOFF
   uint32_t rank_me, rank_n;
+  uint32_t reference_owner;  // owner shard = the reference's get_kmer_target_rank instead of the k-mer hash
   // MODE_BIN
   uint64_t *records;
   uint64_t seg_capacity;
@@ -314,7 +315,8 @@ __device__ __forceinline__ void stage_tile(TileLDS &L, const ExtractArgs &a, int
 // window [lp-1, lp+k] crosses a read boundary (S1, S5).  rec = canonical k-mer (S3, S4) with the
 // extension codes (S5) in the low 6 bits of its last word; h = hash of the bare k-mer.
 template <int NL>
-__device__ __forceinline__ bool tile_kmer(const TileLDS &L, int lp, int k, uint64_t (&rec)[NL], uint64_t &h) {
+__device__ __forceinline__ bool tile_kmer(const TileLDS &L, int lp, int k, uint64_t (&rec)[NL], uint64_t &h, uint32_t rank_n = 1,
+                                          uint32_t reference_owner = 0, uint32_t *owner = nullptr) {
   {  // any boundary among gaps lp .. lp+k ?
     int rem = k + 1, w = lp >> 5, s = lp & 31;
     uint32_t badbits = L.gap[w] >> s;
@@ -344,6 +346,8 @@ __device__ __forceinline__ bool tile_kmer(const TileLDS &L, int lp, int k, uint6
   uint32_t rc = (uint32_t)(W[pr >> 5] >> (62 - 2 * (pr & 31))) & 3u;
   uint32_t le = ((L.ok[pl >> 4] >> (pl & 15)) & 1u) ? lc : KC_EXT_NONE;
   uint32_t re = ((L.ok[pr >> 4] >> (pr & 15)) & 1u) ? rc : KC_EXT_NONE;
+  if (owner) *owner = 0;
+  if (owner && rank_n > 1 && reference_owner) *owner = kc_reference_owner<NL>(f, r, k, rank_n);
   if (kc_less<NL>(r, f)) {  // strict: a palindrome keeps the forward extensions
 #pragma unroll
     for (int j = 0; j < NL; j++) f[j] = r[j];
@@ -353,6 +357,7 @@ __device__ __forceinline__ bool tile_kmer(const TileLDS &L, int lp, int k, uint6
     re = nr;
   }
   h = kc_hash<NL>(f);
+  if (owner && rank_n > 1 && !reference_owner) *owner = kc_owner_of_hash(h, rank_n);
 #pragma unroll
   for (int j = 0; j < NL; j++) rec[j] = f[j];
   rec[NL - 1] |= (uint64_t)(le | (re << 3));
@@ -371,9 +376,8 @@ __global__ __launch_bounds__(TPB) void kc_extract_kernel(ExtractArgs a, Table t,
     const int off = it * TPB + threadIdx.x;
     const int64_t x = T0 + off;
     uint64_t rec[NL], h = 0;
-    bool valid = (x > lo) && (x + a.k < hi) && tile_kmer<NL>(L, PRE + off, a.k, rec, h);
     uint32_t owner = 0;
-    if (valid && a.rank_n > 1) owner = kc_owner_of_hash(h, a.rank_n);
+    bool valid = (x > lo) && (x + a.k < hi) && tile_kmer<NL>(L, PRE + off, a.k, rec, h, a.rank_n, a.reference_owner, &owner);
     if (valid && owner == a.rank_me) {
       table_insert<NL>(t, rec, ctrs);
       n_ins++;

@@ -54,10 +54,11 @@ class KmerCounter:
     """One shard (one GPU) of the k-mer analysis stage."""
 
     def __init__(self, kmer_len, qual_offset=33, dmin_thres=2, device=0, rank_me=0, rank_n=1, max_elems=0, time_kernels=False,
-                 max_kmers_buffered=0, tuning=None):
+                 max_kmers_buffered=0, tuning=None, reference_owner=False):
         L = lib()
         cfg = kc_config(kmer_len=kmer_len, qual_offset=qual_offset, dmin_thres=dmin_thres, device=device, rank_me=rank_me,
-                        rank_n=rank_n, max_elems=max_elems, flags=_lib.KC_FLAG_TIME_KERNELS if time_kernels else 0, reserved=0,
+                        rank_n=rank_n, max_elems=max_elems, flags=(_lib.KC_FLAG_TIME_KERNELS if time_kernels else 0) | (_lib.KC_FLAG_REFERENCE_OWNER if reference_owner else 0),
+                        reserved=0,
                         max_kmers_buffered=max_kmers_buffered)
         st = C.c_int(0)
         self._h = L.kc_create(C.byref(cfg), C.byref(st))

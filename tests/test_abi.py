@@ -82,3 +82,22 @@ def test_host_synth_reads_shape_and_determinism():
     assert set(bytes(b1)) <= set(b"ACGTN") and set(bytes(q1)) <= set(b"I#")
     err = (q1 == ord("#")).mean()
     assert 0.005 < err < 0.05
+
+
+def test_reference_owner_matches_oracle_target_rank():
+    """kc_owner_reference is the reference's get_kmer_target_rank (kmer_dht.cpp:192-196), whose restatement in
+    the oracle is pinned by the SURVEY known answers for minimizer_hash_fast."""
+    from oracle import cpu_oracle as O
+    L = pkg.lib()
+    rng = np.random.default_rng(4)
+    for k in (21, 33, 51, 55, 77, 99):
+        m = O.lib().orc_minimizer_len(k)
+        for _ in range(200):
+            s = "".join(rng.choice(list("ACGT"), size=k))
+            w = O.pack_kmer(s)
+            rc = O.revcomp(w, k)
+            canon = rc if tuple(rc) < tuple(w) else w
+            for n in (2, 8, 13):
+                want = O.target_rank(canon, k, m, n)
+                assert L.kc_owner_reference(canon.ctypes.data, k, n) == want
+                assert L.kc_owner_reference(np.ascontiguousarray(w).ctypes.data, k, n) == want  # strand-independent

@@ -402,3 +402,37 @@ def test_packed_reads_ingest_matches_oracle(k, tuning):
             kc.submit_packed_reads(bad, offs)
             kc.results()
         assert e.value.status == -7
+
+
+@pytest.mark.parametrize("k", [21, 51, 77])
+def test_reference_owner_mode_bins_like_get_kmer_target_rank(k):
+    """KC_FLAG_REFERENCE_OWNER: every record lands in the segment of the rank the reference's own
+    KmerDHT::get_kmer_target_rank would send it to (oracle restatement, pinned by the SURVEY known answers), and the
+    sharded flow still reproduces the oracle's result."""
+    import torch
+    nl = pkg.lib().kc_num_longs(k)
+    m = O.lib().orc_minimizer_len(k)
+    rng = np.random.default_rng(60 + k)
+    reads, quals = random_reads(rng, 600, min_len=k, max_len=k + 100, genome_len=2000)
+    b, q, offs = arrays(reads, quals)
+    want, _, wst = oracle_run(b, q, offs, k)
+    R = 5
+    shards = [pkg.KmerCounter(k, rank_me=r, rank_n=R, reference_owner=True) for r in range(R)]
+    seg = int(wst["kmers_inserted"])
+    recs = torch.zeros(R * seg * nl, dtype=torch.int64, device="cuda")
+    counts = shards[0].extract_partition(b, q, offs, recs, seg)
+    assert int(counts.sum()) == wst["kmers_inserted"] and (counts > 0).all()
+    host = recs.cpu().numpy().view(np.uint64).reshape(R, seg, nl)
+    for d in range(R):
+        seg_recs = host[d, :int(counts[d])].copy()
+        seg_recs[:, nl - 1] &= ~np.uint64(0x3F)
+        for row in seg_recs[::53]:
+            assert O.target_rank(np.ascontiguousarray(row), k, m, R) == d
+        shards[d].insert_records(recs[d * seg * nl:], int(counts[d]))
+    parts = [s.sorted_results() for s in shards]
+    keys = np.concatenate([p[0] for p in parts])
+    order = np.lexsort([keys[:, j] for j in range(nl - 1, -1, -1)])
+    got = tuple(np.concatenate([p[i] for p in parts])[order] for i in range(4))
+    assert_same(got, want)
+    for s in shards:
+        s.close()

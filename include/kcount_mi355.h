@@ -191,6 +191,11 @@ int kc_flush(kc_ctx *ctx);
 int kc_finalize(kc_ctx *ctx, kc_result *out);
 /* begin_iterate/get_next_entry in bulk: copy the results to host arrays sized from kc_result.n. */
 int kc_copy_results(kc_ctx *ctx, uint64_t *keys, uint16_t *counts, uint8_t *left, uint8_t *right);
+/* KmerDHT::kmer_exists / get_kmer_count / get_local_kmer_counts (src/kcount/kmer_dht.cpp:198-245) in bulk, against the
+ * results kept in HBM: nq k-mers of num_longs words each, in either orientation; counts[i] = 0 (and left/right = 0)
+ * when the k-mer did not survive.  The index over the results is built on the first call after kc_finalize.
+ * left/right may be NULL.  on_device != 0: all pointers are device pointers. */
+int kc_lookup(kc_ctx *ctx, const uint64_t *queries, uint64_t nq, int on_device, uint16_t *counts, uint8_t *left, uint8_t *right);
 /* Every table entry before the purge, for tests of S5/S6: keys[n*num_longs], counts[n] (clipped to 65535),
  * exts[n*8] = left ACGT then right ACGT.  Call with NULLs to get n. */
 int kc_dump_table(kc_ctx *ctx, uint64_t *keys, uint16_t *counts, uint16_t *exts, uint64_t *n);

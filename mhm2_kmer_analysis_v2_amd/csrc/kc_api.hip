@@ -71,6 +71,8 @@ struct kc_ctx {
   uint8_t *d_out_left, *d_out_right;
   uint64_t out_cap, out_n;
   bool finalized;
+  uint32_t *d_index;  // lookup index over the results (built on first kc_lookup)
+  uint64_t index_cap;
   kc_synth_table *d_synth;
   // host-side stats
   uint64_t num_reads, num_bases, num_gpu_calls;
@@ -330,7 +332,14 @@ extern "C" kc_ctx *kc_create(const kc_config *cfg, int *status) {
   return c;
 }
 
+static void free_index(kc_ctx *c) {
+  if (c->d_index) (void)hipFree(c->d_index);
+  c->d_index = nullptr;
+  c->index_cap = 0;
+}
+
 static void free_results(kc_ctx *c) {
+  free_index(c);
   if (c->d_out_keys) (void)hipFree(c->d_out_keys);
   if (c->d_out_counts) (void)hipFree(c->d_out_counts);
   if (c->d_out_left) (void)hipFree(c->d_out_left);
@@ -999,6 +1008,7 @@ static int alloc_results(kc_ctx *c, uint64_t cap) {
   if (!cap) cap = 1;
   if (c->d_out_keys && c->out_cap >= cap) {  // the arrays of an earlier run are big enough: keep them
     c->out_n = 0;
+    free_index(c);
     return KC_OK;
   }
   free_results(c);
@@ -1411,6 +1421,63 @@ extern "C" int kc_set_tuning(kc_ctx *c, const kc_tuning *t) {
   c->tuning = *t;
   bk_free(c);  // the geometry is chosen again at the first submit
   return KC_OK;
+}
+
+template <int NL>
+static int lookup_t(kc_ctx *c, const uint64_t *dq, uint64_t nq, uint16_t *dc, uint8_t *dl, uint8_t *dr) {
+  if (!c->d_index) {
+    if (c->out_n >= 0xFFFFFFFFull) return KC_ERR_CAPACITY;
+    uint64_t cap = next_pow2(std::max<uint64_t>(1024, c->out_n * 2));
+    HIPCHK(hipMalloc((void **)&c->d_index, cap * 4));
+    c->index_cap = cap;
+    HIPCHK(hipMemsetAsync(c->d_index, 0, cap * 4, c->stream));
+    if (c->out_n) {
+      hipLaunchKernelGGL(kc_index_build_kernel<NL>, dim3((unsigned)((c->out_n + 255) / 256)), dim3(256), 0, c->stream, c->d_out_keys,
+                         c->out_n, c->d_index, cap - 1);
+      c->num_gpu_calls++;
+      HIPCHK(hipGetLastError());
+    }
+  }
+  if (nq) {
+    hipLaunchKernelGGL(kc_lookup_kernel<NL>, dim3((unsigned)((nq + 255) / 256)), dim3(256), 0, c->stream, dq, nq, c->k, c->d_index,
+                       c->index_cap - 1, c->d_out_keys, c->d_out_counts, c->d_out_left, c->d_out_right, dc, dl, dr);
+    c->num_gpu_calls++;
+    HIPCHK(hipGetLastError());
+  }
+  return KC_OK;
+}
+
+extern "C" int kc_lookup(kc_ctx *c, const uint64_t *queries, uint64_t nq, int on_device, uint16_t *counts, uint8_t *left, uint8_t *right) {
+  if (!c || (nq && (!queries || !counts))) return KC_ERR_INVALID_ARG;
+  if (!c->finalized) return KC_ERR_STATE;
+  HIPCHK(hipSetDevice(c->cfg.device));
+  const uint64_t *dq = queries;
+  uint64_t *sq = nullptr;
+  uint16_t *dc = counts;
+  uint8_t *dl = left, *dr = right;
+  if (!on_device && nq) {
+    HIPCHK(hipMalloc((void **)&sq, nq * c->nl * 8 + nq * 4));
+    HIPCHK(hipMemcpyAsync(sq, queries, nq * c->nl * 8, hipMemcpyHostToDevice, c->stream));
+    dq = sq;
+    dc = (uint16_t *)(sq + nq * c->nl);
+    dl = (uint8_t *)(dc + nq);
+    dr = dl + nq;
+  }
+  int rc;
+  switch (c->nl) {
+    case 1: rc = lookup_t<1>(c, dq, nq, dc, dl, dr); break;
+    case 2: rc = lookup_t<2>(c, dq, nq, dc, dl, dr); break;
+    case 3: rc = lookup_t<3>(c, dq, nq, dc, dl, dr); break;
+    default: rc = lookup_t<4>(c, dq, nq, dc, dl, dr); break;
+  }
+  if (!rc && !on_device && nq) {
+    HIPCHK(hipStreamSynchronize(c->stream));
+    HIPCHK(hipMemcpy(counts, dc, nq * 2, hipMemcpyDeviceToHost));
+    if (left) HIPCHK(hipMemcpy(left, dl, nq, hipMemcpyDeviceToHost));
+    if (right) HIPCHK(hipMemcpy(right, dr, nq, hipMemcpyDeviceToHost));
+  }
+  if (sq) (void)hipFree(sq);
+  return rc;
 }
 
 extern "C" int kc_get_kernel_times(kc_ctx *c, kc_kernel_time *out, int max, int *n) {

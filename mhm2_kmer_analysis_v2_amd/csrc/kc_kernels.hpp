@@ -562,6 +562,51 @@ __global__ void kc_rehash_kernel(Table from, uint64_t from_capacity, Table to) {
   for (int i = 0; i < 9; i++) to.vals[slot * 9 + i] = from.vals[s * 9 + i];
 }
 
+// ---- lookups over the results (KmerDHT::kmer_exists / get_kmer_count, src/kcount/kmer_dht.cpp:198-245) -------------
+// index: open addressing over result numbers (slot = result index + 1, 0 = empty), built once after finalize
+template <int NL>
+__global__ void kc_index_build_kernel(const uint64_t *keys, uint64_t n, uint32_t *index, uint64_t mask) {
+  const uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= n) return;
+  uint64_t key[NL];
+  for (int j = 0; j < NL; j++) key[j] = keys[i * NL + j];
+  uint64_t s = kc_hash<NL>(key) & mask;
+  while (atomicCAS(&index[s], 0u, (uint32_t)(i + 1)) != 0u) s = (s + 1) & mask;  // result keys are unique
+}
+
+// queries may be given in either orientation; counts[i] = 0 and left/right = 0 when the k-mer is not in the results
+template <int NL>
+__global__ void kc_lookup_kernel(const uint64_t *queries, uint64_t nq, int k, const uint32_t *index, uint64_t mask, const uint64_t *keys,
+                                 const uint16_t *counts, const uint8_t *left, const uint8_t *right, uint16_t *out_counts,
+                                 uint8_t *out_left, uint8_t *out_right) {
+  const uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= nq) return;
+  uint64_t f[NL], r[NL];
+  for (int j = 0; j < NL; j++) f[j] = queries[i * NL + j] & kc_word_mask(k, j);
+  kc_revcomp<NL>(f, k, r);
+  if (kc_less<NL>(r, f))
+    for (int j = 0; j < NL; j++) f[j] = r[j];
+  uint64_t s = kc_hash<NL>(f) & mask;
+  uint16_t c = 0;
+  uint8_t l = 0, rr = 0;
+  for (;;) {
+    const uint32_t e = index[s];
+    if (!e) break;
+    bool same = true;
+    for (int j = 0; j < NL; j++) same &= keys[(uint64_t)(e - 1) * NL + j] == f[j];
+    if (same) {
+      c = counts[e - 1];
+      l = left[e - 1];
+      rr = right[e - 1];
+      break;
+    }
+    s = (s + 1) & mask;
+  }
+  out_counts[i] = c;
+  if (out_left) out_left[i] = l;
+  if (out_right) out_right[i] = rr;
+}
+
 // ---- synthetic reads ----------------------------------------------------------------------------
 __global__ void kc_synth_kernel(const kc_synth_table *tab, uint64_t first_read, uint64_t nreads, uint8_t *bases,
                                 uint8_t *quals, uint64_t *offsets) {

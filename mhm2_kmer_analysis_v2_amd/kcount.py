@@ -169,6 +169,18 @@ class KmerCounter:
               "kc_copy_results")
         return keys, counts, left, right
 
+    def lookup(self, queries):
+        """queries: (n, num_longs) uint64 k-mers in either orientation (host array).  Returns counts u16, left u8,
+        right u8; count 0 = not among the results (KmerDHT::get_kmer_count, kmer_dht.cpp:228-245)."""
+        self.finalize()
+        qa = np.ascontiguousarray(queries, dtype=np.uint64).reshape(-1, self.nl)
+        n = len(qa)
+        counts = np.zeros(n, dtype=np.uint16)
+        left = np.zeros(n, dtype=np.uint8)
+        right = np.zeros(n, dtype=np.uint8)
+        check(lib().kc_lookup(self._h, qa.ctypes.data, n, 0, counts.ctypes.data, left.ctypes.data, right.ctypes.data), "kc_lookup")
+        return counts, left, right
+
     def sorted_results(self):
         keys, counts, left, right = self.results()
         order = np.lexsort([keys[:, j] for j in range(self.nl - 1, -1, -1)]) if len(counts) else np.zeros(0, dtype=np.int64)
@@ -210,6 +222,21 @@ class KmerCounter:
         keys, counts, left, right = self.sorted_results()
         return ["%s %d %s %s" % (kmer_to_string(keys[i], self.k), counts[i], chr(left[i]), chr(right[i]))
                 for i in range(len(counts))]
+
+
+    def dump_kmers(self, directory=".", rank=None):
+        """KmerDHT::dump_kmers (src/kcount/kmer_dht.cpp:273-297): per-rank gzip text file "kmers-<k>.txt.gz", one
+        "KMER count L R" line per k-mer.  Returns the path."""
+        import gzip
+        import os
+        r = self.rank_me if rank is None else rank
+        d = os.path.join(directory, "rank_%d" % r) if self.rank_n > 1 else directory
+        os.makedirs(d, exist_ok=True)
+        path = os.path.join(d, "kmers-%d.txt.gz" % self.k)
+        with gzip.open(path, "wt") as f:
+            for line in self.dump_lines():
+                f.write(line + "\n")
+        return path
 
 
 def kmer_to_string(words, k):

@@ -436,3 +436,31 @@ def test_reference_owner_mode_bins_like_get_kmer_target_rank(k):
     assert_same(got, want)
     for s in shards:
         s.close()
+
+
+@pytest.mark.parametrize("k", [21, 51])
+def test_lookup_over_results(k):
+    """kc_lookup = KmerDHT::get_kmer_count in bulk: every result is found with its count and extensions from either
+    strand; purged and never-seen k-mers come back with count 0."""
+    rng = np.random.default_rng(70 + k)
+    reads, quals = random_reads(rng, 800, min_len=k + 2, max_len=k + 100, genome_len=2500)
+    b, q, offs = arrays(reads, quals)
+    want, wtable, _ = oracle_run(b, q, offs, k)
+    with pkg.KmerCounter(k) as kc:
+        kc.submit_reads(b, q, offs)
+        keys, counts, left, right = kc.sorted_results()
+        c, l, r = kc.lookup(keys)
+        assert (c == counts).all() and (l == left).all() and (r == right).all()
+        rcq = np.stack([O.revcomp(keys[i], k) for i in range(0, len(keys), 7)])  # the other strand finds the same entry
+        c2, l2, r2 = kc.lookup(rcq)
+        assert (c2 == counts[::7]).all() and (l2 == left[::7]).all()
+        # k-mers that were counted but purged, and random ones: absent
+        kept = {tuple(int(x) for x in row) for row in keys}
+        purged = np.stack([row for row in wtable[0] if tuple(int(x) for x in row) not in kept][:500])
+        c3, _, _ = kc.lookup(purged)
+        assert (c3 == 0).all()
+        rnd = np.stack([O.pack_kmer("".join(rng.choice(list("ACGT"), size=k))) for _ in range(200)])
+        c4, _, _ = kc.lookup(rnd)
+        assert (c4 == 0).sum() >= 199
+        c5, _, _ = kc.lookup(np.zeros((0, kc.nl), dtype=np.uint64))
+        assert len(c5) == 0

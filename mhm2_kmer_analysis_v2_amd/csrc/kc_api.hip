@@ -536,14 +536,13 @@ template <int NL> static size_t lds_l1_records() { return ((sizeof(L1RLDS) + 15)
 template <int NL> static size_t lds_l2() { return ((sizeof(L2LDS) + 15) & ~size_t(15)) + Rnd<NL>::STAGE; }
 
 template <int NL, int FMT>
-static int launch_l1_reads_t(kc_ctx *c, const ExtractArgs &a, uint64_t ntiles) {
+static int launch_l1_reads_t(kc_ctx *c, const ExtractArgs &a, uint64_t nsuper) {
   auto kern = kc_l1_reads_kernel<NL, FMT>;
   int rc = set_dyn_lds(kern, lds_l1_reads<NL>());
   if (rc) return rc;
-  const uint64_t nsuper = (ntiles + QUARTERS - 1) / QUARTERS;
   const unsigned grid = (unsigned)std::min<uint64_t>(c->gm.G, nsuper);
   KernelTimer kt(c, KT_L1_READS);
-  hipLaunchKernelGGL(kern, dim3(grid), dim3(WGB), lds_l1_reads<NL>(), c->stream, a, c->gm, c->bb, ntiles, c->bk_rot, c->d_ctrs, c->d_cb);
+  hipLaunchKernelGGL(kern, dim3(grid), dim3(WGB), lds_l1_reads<NL>(), c->stream, a, c->gm, c->bb, nsuper, c->bk_rot, c->d_ctrs, c->d_cb);
   c->bk_rot = (uint32_t)((c->bk_rot + nsuper) % c->gm.G);
   return KC_OK;
 }
@@ -555,6 +554,14 @@ static int launch_l1_reads(kc_ctx *c, const ExtractArgs &a, uint64_t ntiles, int
       case 2: return launch_l1_reads_t<2, FMT_READS>(c, a, ntiles);
       case 3: return launch_l1_reads_t<3, FMT_READS>(c, a, ntiles);
       default: return launch_l1_reads_t<4, FMT_READS>(c, a, ntiles);
+    }
+  }
+  if (fmt == FMT_READS_UQ) {
+    switch (c->nl) {
+      case 1: return launch_l1_reads_t<1, FMT_READS_UQ>(c, a, ntiles);
+      case 2: return launch_l1_reads_t<2, FMT_READS_UQ>(c, a, ntiles);
+      case 3: return launch_l1_reads_t<3, FMT_READS_UQ>(c, a, ntiles);
+      default: return launch_l1_reads_t<4, FMT_READS_UQ>(c, a, ntiles);
     }
   }
   if (fmt == FMT_PACKED) {
@@ -574,14 +581,13 @@ static int launch_l1_reads(kc_ctx *c, const ExtractArgs &a, uint64_t ntiles, int
 }
 
 template <int NL, int FMT>
-static int launch_bin_reads_t(kc_ctx *c, const ExtractArgs &a, uint64_t ntiles) {
+static int launch_bin_reads_t(kc_ctx *c, const ExtractArgs &a, uint64_t nsuper) {
   auto kern = kc_bin_reads_kernel<NL, FMT>;
   int rc = set_dyn_lds(kern, lds_l1_reads<NL>());
   if (rc) return rc;
-  const uint64_t nsuper = (ntiles + QUARTERS - 1) / QUARTERS;
   const unsigned grid = (unsigned)std::min<uint64_t>((uint64_t)c->num_cus, nsuper);
   KernelTimer kt(c, KT_EXTRACT_BIN);
-  hipLaunchKernelGGL(kern, dim3(grid), dim3(WGB), lds_l1_reads<NL>(), c->stream, a, ntiles, c->d_ctrs);
+  hipLaunchKernelGGL(kern, dim3(grid), dim3(WGB), lds_l1_reads<NL>(), c->stream, a, nsuper, c->d_ctrs);
   return KC_OK;
 }
 
@@ -592,6 +598,14 @@ static int launch_bin_reads(kc_ctx *c, const ExtractArgs &a, uint64_t ntiles, in
       case 2: return launch_bin_reads_t<2, FMT_READS>(c, a, ntiles);
       case 3: return launch_bin_reads_t<3, FMT_READS>(c, a, ntiles);
       default: return launch_bin_reads_t<4, FMT_READS>(c, a, ntiles);
+    }
+  }
+  if (fmt == FMT_READS_UQ) {
+    switch (c->nl) {
+      case 1: return launch_bin_reads_t<1, FMT_READS_UQ>(c, a, ntiles);
+      case 2: return launch_bin_reads_t<2, FMT_READS_UQ>(c, a, ntiles);
+      case 3: return launch_bin_reads_t<3, FMT_READS_UQ>(c, a, ntiles);
+      default: return launch_bin_reads_t<4, FMT_READS_UQ>(c, a, ntiles);
     }
   }
   if (fmt == FMT_PACKED) {
@@ -688,6 +702,7 @@ static void launch_extract_m(kc_ctx *c, const ExtractArgs &a, unsigned ntiles) {
 static void launch_extract(kc_ctx *c, const ExtractArgs &a, unsigned ntiles, int fmt) {
   KernelTimer kt(c, KT_EXTRACT_INSERT);
   if (fmt == FMT_READS) launch_extract_m<FMT_READS>(c, a, ntiles);
+  else if (fmt == FMT_READS_UQ) launch_extract_m<FMT_READS_UQ>(c, a, ntiles);
   else if (fmt == FMT_PACKED) launch_extract_m<FMT_PACKED>(c, a, ntiles);
   else launch_extract_m<FMT_SEQBLOCK>(c, a, ntiles);
 }
@@ -704,7 +719,7 @@ static int run_extract_device(kc_ctx *c, const uint8_t *bases, const uint8_t *qu
   a.bases = bases - a.align;
   if (fmt == FMT_READS) {
     a.quals = quals - a.align;
-    a.quals_vector_ok = (((uintptr_t)a.quals & 15u) == 0) ? 1u : 0u;
+    if (((uintptr_t)a.quals & 15u) != 0) fmt = FMT_READS_UQ;  // not co-aligned with the bases: the byte-load instantiation
   }
   if (fmt != FMT_SEQBLOCK) a.offsets = d_offsets;
   a.nreads = nreads;
@@ -716,7 +731,7 @@ static int run_extract_device(kc_ctx *c, const uint8_t *bases, const uint8_t *qu
   a.reference_owner = (c->cfg.flags & KC_FLAG_REFERENCE_OWNER) ? 1u : 0u;
   a.records = d_records;
   a.seg_capacity = seg_capacity;
-  const uint64_t ntiles_total = (a.align + total + TILE - 1) / TILE;
+  const int64_t end = (int64_t)a.align + (int64_t)total;  // aligned coordinate one past the last real byte
   bool over_capacity = false;
   if (mode == MODE_INSERT) {
     c->started = true;
@@ -730,25 +745,27 @@ static int run_extract_device(kc_ctx *c, const uint8_t *bases, const uint8_t *qu
       over_capacity = c->h_ctrs[CTR_EXPECT] > c->bk_capacity;
     }
   }
-  uint64_t t0 = 0;
-  while (t0 < ntiles_total) {
+  int64_t p0 = 0;  // tiles of every launch start here; the bucketed kernels and the table kernel differ in tile span
+  while (p0 < end) {
     const bool bk = (mode == MODE_INSERT) && bk_active(c);
+    const bool super = bk || mode == MODE_BIN;
+    const uint64_t span = super ? (uint64_t)SUPER_SPAN : (uint64_t)TILE;
     uint64_t chunk_tiles;
-    if (bk || mode == MODE_BIN) {
-      chunk_tiles = (1ULL << 31) / TILE;
+    if (super) {
+      chunk_tiles = (1ULL << 31) / span;
     } else {
       // a chunk may add at most one new entry per position: keep it within a quarter of the table
-      chunk_tiles = std::max<uint64_t>(64, (c->capacity / 4) / TILE);
-      chunk_tiles = std::min<uint64_t>(chunk_tiles, (1ULL << 28) / TILE);
+      chunk_tiles = std::max<uint64_t>(64, (c->capacity / 4) / span);
+      chunk_tiles = std::min<uint64_t>(chunk_tiles, (1ULL << 28) / span);
     }
-    const uint64_t nt = std::min(chunk_tiles, ntiles_total - t0);
+    const uint64_t nt = std::min<uint64_t>(chunk_tiles, ((uint64_t)(end - p0) + span - 1) / span);
     if (bk && over_capacity) {
       int rc = bk_drain_to_table(c);  // out of buffer room: this and every later chunk take the table path
       if (rc) return rc;
       continue;
     }
     if (mode == MODE_INSERT && !bk) {
-      int rc = ensure_room(c, nt * TILE);
+      int rc = ensure_room(c, nt * span);
       if (rc) return rc;
     }
     if (fmt != FMT_SEQBLOCK) {
@@ -757,11 +774,11 @@ static int run_extract_device(kc_ctx *c, const uint8_t *bases, const uint8_t *qu
       {
         KernelTimer kt(c, KT_TILE_FIRST);
         hipLaunchKernelGGL(kc_tile_first_kernel, dim3((unsigned)((nt + 255) / 256)), dim3(256), 0, c->stream, d_offsets, nreads,
-                           a.align, t0, nt, c->d_tile_first);
+                           a.align, p0, (uint32_t)span, nt, c->d_tile_first);
       }
       a.tile_first = c->d_tile_first;
     }
-    a.tile0 = t0;
+    a.pos0 = p0;
     if (bk) {
       int rc = launch_l1_reads(c, a, nt, fmt);
       if (rc) return rc;
@@ -772,8 +789,8 @@ static int run_extract_device(kc_ctx *c, const uint8_t *bases, const uint8_t *qu
       launch_extract(c, a, (unsigned)nt, fmt);
     }
     HIPCHK(hipGetLastError());
-    t0 += nt;
-    if (fmt != FMT_SEQBLOCK && t0 < ntiles_total) HIPCHK(hipStreamSynchronize(c->stream));  // d_tile_first is reused
+    p0 += (int64_t)(nt * span);
+    if (fmt != FMT_SEQBLOCK && p0 < end) HIPCHK(hipStreamSynchronize(c->stream));  // d_tile_first is reused
   }
   return KC_OK;
 }
@@ -1109,6 +1126,9 @@ static int bk_build_regions(kc_ctx *c) {
   fprintf(stderr, "l1 kernel cycles (thread 0, summed over workgroups): extract+hist %llu barrierA %llu scan+reserve %llu scatter %llu copyout %llu stage %llu\n",
           (unsigned long long)c->h_cb[8], (unsigned long long)c->h_cb[9], (unsigned long long)c->h_cb[10],
           (unsigned long long)c->h_cb[11], (unsigned long long)c->h_cb[12], (unsigned long long)c->h_cb[13]);
+  (void)sync_ctrs(c);
+  fprintf(stderr, "   encode: first barrier %llu groups %llu offsets %llu last barrier %llu\n", (unsigned long long)c->h_ctrs[CTR_BIN0 + 40],
+          (unsigned long long)c->h_ctrs[CTR_BIN0 + 41], (unsigned long long)c->h_ctrs[CTR_BIN0 + 42], (unsigned long long)c->h_ctrs[CTR_BIN0 + 43]);
   HIPCHK(hipMemsetAsync(c->d_cb + 8, 0, 8 * 8, c->stream));
 #endif
   switch (c->nl) {

@@ -29,7 +29,11 @@
 namespace kc {
 
 constexpr int WGB = 1024;        // threads per workgroup in this file (16 waves: one workgroup per CU)
-constexpr int QUARTERS = WGB / TPB;
+// The reads kernels stage one "super-tile" per workgroup and step: exactly one sixteen-base group per thread (the
+// staged span, PRE + SUPER_SPAN + POST, is 16 * WGB positions), k-mers starting at its SUPER_SPAN positions.
+constexpr int SUPER_SPAN = 16 * WGB - PRE - POST;  // 16160
+using TileSuper = TileGeo<WGB, SUPER_SPAN>;
+static_assert(TileSuper::GPT == 1 && TileSuper::NGROUP == WGB, "one group per thread");
 constexpr int PMAX = 1024;       // max fan-out of either level
 constexpr int GMAX = 512;        // max level-1 writers
 
@@ -290,7 +294,7 @@ __device__ __forceinline__ ChainState split_load_state(SplitLDS &L, uint32_t P, 
 
 // ---- level 1 from reads ---------------------------------------------------------------------------
 struct L1LDS {
-  TileLDS tile[QUARTERS];
+  TileLDS<TileSuper> tile;
   SplitLDS sp;
 };
 
@@ -322,14 +326,14 @@ __device__ __forceinline__ void l1_overflow(const BucketBufs &bb, uint64_t *cb, 
 }
 
 template <int NL, int FMT>
-__global__ __launch_bounds__(WGB) void kc_l1_reads_kernel(ExtractArgs a, Geom gm, BucketBufs bb, uint64_t ntiles, uint32_t rot,
+__global__ __launch_bounds__(WGB) void kc_l1_reads_kernel(ExtractArgs a, Geom gm, BucketBufs bb, uint64_t nsuper, uint32_t rot,
                                                           uint64_t *ctrs, uint64_t *cb) {
   extern __shared__ __align__(16) uint8_t smem[];
   L1LDS &L = *reinterpret_cast<L1LDS *>(smem);
   uint64_t *sorted = reinterpret_cast<uint64_t *>(smem + ((sizeof(L1LDS) + 15) & ~size_t(15)));
   uint16_t *sbucket = reinterpret_cast<uint16_t *>(smem + ((sizeof(L1LDS) + 15) & ~size_t(15)) + Rnd<NL>::STAGE_READS);
   constexpr int RPOS = Rnd<NL>::RPOS_READS;
-  const int tid = threadIdx.x, q = tid >> 8, qt = tid & (TPB - 1);
+  const int tid = threadIdx.x;
   // writer id: launches rotate their first writer (rot) so that many small submits still spread evenly
   const uint32_t g = (blockIdx.x + rot) % gm.G, P1 = gm.P1;
   ChainDest D = l1_dest<NL>(gm, bb, g);
@@ -340,41 +344,41 @@ __global__ __launch_bounds__(WGB) void kc_l1_reads_kernel(ExtractArgs a, Geom gm
 #endif
   ChainState cst = split_load_state(L.sp, P1, bb.cnt1 + (size_t)g * P1, D.chain, D.LMAX, D.log2CH, 0, bb.used1[g]);
   __syncthreads();
-  const int64_t lo = a.align, hi = (int64_t)a.align + (int64_t)a.total;
-  const uint64_t nsuper = (ntiles + QUARTERS - 1) / QUARTERS;
   uint32_t n_ins = 0;
   int buf = 0;
-  // the bytes of the next super-tile are on their way while this one is processed
-  TileRaw raw;
-  {
-    const uint64_t tile = (uint64_t)blockIdx.x * QUARTERS + q;
-    const bool active = blockIdx.x < nsuper && tile < ntiles;
-    tile_prefetch<FMT>(raw, a, (int64_t)(a.tile0 + tile) * TILE, qt, (active && FMT != FMT_SEQBLOCK) ? a.tile_first[tile] : 0, active);
-  }
+  // the bytes of the next super-tile are on their way while this one is processed; the first read of a super-tile is
+  // looked up one step further ahead than the bytes, which need it for their addresses
+  TileRaw<TileSuper> raw;
+  auto first_of = [&](uint64_t st) -> uint64_t { return (FMT != FMT_SEQBLOCK && st < nsuper) ? a.tile_first[st] : 0; };
+  tile_prefetch<FMT, TileSuper>(raw, a, a.pos0 + (int64_t)blockIdx.x * SUPER_SPAN, tid, first_of(blockIdx.x), blockIdx.x < nsuper);
+  uint64_t next_first = first_of((uint64_t)blockIdx.x + gridDim.x);
+  constexpr int RUNS = SUPER_SPAN / RPOS;  // runs of RPOS consecutive positions in a super-tile
+  static_assert(SUPER_SPAN % RPOS == 0, "runs must tile the span");
   for (uint64_t st = blockIdx.x; st < nsuper; st += gridDim.x) {
-    const uint64_t tile = st * QUARTERS + q;
-    const bool active = tile < ntiles;
-    const int64_t T0 = (int64_t)(a.tile0 + tile) * TILE;
-    tile_encode<FMT>(L.tile[q], raw, a, T0, ctrs, qt, active);
+    const int64_t T0 = a.pos0 + (int64_t)st * SUPER_SPAN;
+    tile_encode<FMT, TileSuper>(L.tile, raw, a, T0, ctrs, tid, true);
     {
-      const uint64_t nst = st + gridDim.x, ntile = nst * QUARTERS + q;
-      const bool nactive = nst < nsuper && ntile < ntiles;
-      tile_prefetch<FMT>(raw, a, (int64_t)(a.tile0 + ntile) * TILE, qt, (nactive && FMT != FMT_SEQBLOCK) ? a.tile_first[ntile] : 0, nactive);
+      const uint64_t nst = st + gridDim.x;
+      tile_prefetch<FMT, TileSuper>(raw, a, a.pos0 + (int64_t)nst * SUPER_SPAN, tid, next_first, nst < nsuper);
+      next_first = first_of(nst + gridDim.x);
     }
-    KC_SPLIT_STAMP(5)  // stage the tiles
+    KC_SPLIT_STAMP(5)  // stage the super-tile
 #pragma unroll 1
-    for (int round = 0; round < PPT / RPOS; round++) {
+    for (int round = 0; round < (RUNS + WGB - 1) / WGB; round++) {
       uint64_t rec[RPOS][NL];
       uint32_t br[RPOS];
+      // each thread walks RPOS consecutive positions
+      const int run_id = round * WGB + tid;
+      const bool active = run_id < RUNS;
+      const int lp0 = PRE + (active ? run_id : 0) * RPOS;
+      KmerRun<NL> run;
+      run_begin<NL>(run, L.tile, lp0, a.k);
 #pragma unroll
       for (int j = 0; j < RPOS; j++) {
-        const int off = (round * RPOS + j) * TPB + qt;
-        const int64_t x = T0 + off;
         uint64_t h = 0;
         uint32_t owner = 0;
-        bool valid = active && (x > lo) && (x + a.k < hi) &&
-                     tile_kmer<NL>(L.tile[q], PRE + off, a.k, rec[j], h, a.rank_n, a.reference_owner, &owner);
-        if (valid && a.rank_n > 1) valid = owner == a.rank_me;
+        bool valid = run_kmer<NL>(run, j, lp0, a.k, rec[j], h, a.rank_n, a.reference_owner, &owner) && active;
+        if (a.rank_n > 1) valid = valid && owner == a.rank_me;
         br[j] = ~0u;
         if (valid) {
           const uint32_t b = hash_b1(h, gm);
@@ -382,8 +386,9 @@ __global__ __launch_bounds__(WGB) void kc_l1_reads_kernel(ExtractArgs a, Geom gm
           br[j] = b | (rank << 10);
           n_ins++;
         }
+        if (j + 1 < RPOS) run_advance<NL>(run, j, lp0, a.k);
       }
-      KC_SPLIT_STAMP(0)  // cut the k-mers out of the tiles, histogram
+      KC_SPLIT_STAMP(0)  // cut the k-mers out of the super-tile, histogram
       lds_barrier();
       split_round<NL, RPOS>(
           L.sp, sorted, sbucket, buf, P1, rec, br, D, cst, [&](uint64_t h) { return hash_b1(h, gm); },
@@ -449,50 +454,48 @@ __device__ __forceinline__ void split_round_flat(SplitLDS &L, uint64_t *sorted, 
 }
 
 template <int NL, int FMT>
-__global__ __launch_bounds__(WGB) void kc_bin_reads_kernel(ExtractArgs a, uint64_t ntiles, uint64_t *ctrs) {
+__global__ __launch_bounds__(WGB) void kc_bin_reads_kernel(ExtractArgs a, uint64_t nsuper, uint64_t *ctrs) {
   extern __shared__ __align__(16) uint8_t smem[];
   L1LDS &L = *reinterpret_cast<L1LDS *>(smem);
   uint64_t *sorted = reinterpret_cast<uint64_t *>(smem + ((sizeof(L1LDS) + 15) & ~size_t(15)));
   constexpr int RPOS = Rnd<NL>::RPOS_READS;
-  const int tid = threadIdx.x, q = tid >> 8, qt = tid & (TPB - 1);
+  const int tid = threadIdx.x;
   const uint32_t P = a.rank_n;
   if ((uint32_t)tid < PMAX) {
     L.sp.hist[0][tid] = 0;
     L.sp.hist[1][tid] = 0;
   }
   __syncthreads();
-  const int64_t lo = a.align, hi = (int64_t)a.align + (int64_t)a.total;
-  const uint64_t nsuper = (ntiles + QUARTERS - 1) / QUARTERS;
   int buf = 0;
-  // the bytes of the next super-tile are on their way while this one is processed
-  TileRaw raw;
-  {
-    const uint64_t tile = (uint64_t)blockIdx.x * QUARTERS + q;
-    const bool active = blockIdx.x < nsuper && tile < ntiles;
-    tile_prefetch<FMT>(raw, a, (int64_t)(a.tile0 + tile) * TILE, qt, (active && FMT != FMT_SEQBLOCK) ? a.tile_first[tile] : 0, active);
-  }
+  TileRaw<TileSuper> raw;  // see kc_l1_reads_kernel
+  auto first_of = [&](uint64_t st) -> uint64_t { return (FMT != FMT_SEQBLOCK && st < nsuper) ? a.tile_first[st] : 0; };
+  tile_prefetch<FMT, TileSuper>(raw, a, a.pos0 + (int64_t)blockIdx.x * SUPER_SPAN, tid, first_of(blockIdx.x), blockIdx.x < nsuper);
+  uint64_t next_first = first_of((uint64_t)blockIdx.x + gridDim.x);
+  constexpr int RUNS = SUPER_SPAN / RPOS;
+  static_assert(SUPER_SPAN % RPOS == 0, "runs must tile the span");
   for (uint64_t st = blockIdx.x; st < nsuper; st += gridDim.x) {
-    const uint64_t tile = st * QUARTERS + q;
-    const bool active = tile < ntiles;
-    const int64_t T0 = (int64_t)(a.tile0 + tile) * TILE;
-    tile_encode<FMT>(L.tile[q], raw, a, T0, ctrs, qt, active);
+    const int64_t T0 = a.pos0 + (int64_t)st * SUPER_SPAN;
+    tile_encode<FMT, TileSuper>(L.tile, raw, a, T0, ctrs, tid, true);
     {
-      const uint64_t nst = st + gridDim.x, ntile = nst * QUARTERS + q;
-      const bool nactive = nst < nsuper && ntile < ntiles;
-      tile_prefetch<FMT>(raw, a, (int64_t)(a.tile0 + ntile) * TILE, qt, (nactive && FMT != FMT_SEQBLOCK) ? a.tile_first[ntile] : 0, nactive);
+      const uint64_t nst = st + gridDim.x;
+      tile_prefetch<FMT, TileSuper>(raw, a, a.pos0 + (int64_t)nst * SUPER_SPAN, tid, next_first, nst < nsuper);
+      next_first = first_of(nst + gridDim.x);
     }
 #pragma unroll 1
-    for (int round = 0; round < PPT / RPOS; round++) {
+    for (int round = 0; round < (RUNS + WGB - 1) / WGB; round++) {
       uint64_t rec[RPOS][NL];
       uint32_t br[RPOS];
+      const int run_id = round * WGB + tid;
+      const bool active = run_id < RUNS;
+      const int lp0 = PRE + (active ? run_id : 0) * RPOS;
+      KmerRun<NL> run;
+      run_begin<NL>(run, L.tile, lp0, a.k);
 #pragma unroll
       for (int j = 0; j < RPOS; j++) {
-        const int off = (round * RPOS + j) * TPB + qt;
-        const int64_t x = T0 + off;
         uint64_t h = 0;
         uint32_t owner = 0;
-        const bool valid = active && (x > lo) && (x + a.k < hi) &&
-                           tile_kmer<NL>(L.tile[q], PRE + off, a.k, rec[j], h, P, a.reference_owner, &owner);
+        const bool valid = run_kmer<NL>(run, j, lp0, a.k, rec[j], h, P, a.reference_owner, &owner) && active;
+        if (j + 1 < RPOS) run_advance<NL>(run, j, lp0, a.k);
         br[j] = ~0u;
         if (valid) {
           const uint32_t b = P > 1 ? owner : 0u;

@@ -97,24 +97,33 @@ KC_HD bool kc_less(const uint64_t (&a)[NL], const uint64_t (&b)[NL]) {
   return false;
 }
 
-KC_HD uint64_t kc_mix64(uint64_t x) {
-  x ^= x >> 33;
-  x *= 0xff51afd7ed558ccdULL;
-  x ^= x >> 33;
-  x *= 0xc4ceb9fe1a85ec53ULL;
-  x ^= x >> 33;
-  return x;
+// One multiply-and-fold step on a pair of 32-bit words (the "mum" of wyhash32): the 64-bit product of the two
+// words, each whitened by a constant, split back into its halves.  A 32x32->64 multiply is one quarter-rate VALU
+// instruction on gfx950; a 64x64 multiply costs four of them, and the hash runs once per k-mer occurrence in each
+// of the three bucketed kernels.
+KC_HD void kc_mum32(uint32_t &a, uint32_t &b, uint32_t ca, uint32_t cb) {
+  const uint64_t c = (uint64_t)(a ^ ca) * (uint64_t)(b ^ cb);
+  a = (uint32_t)c;
+  b = (uint32_t)(c >> 32);
 }
 
-// 64-bit hash of a canonical k-mer (extension bits already cleared).  The high 32
-// bits pick the owner shard, the low bits the table slot, so the two are
-// independent.  Any deterministic function gives the same final set (F3).
+// 64-bit hash of a canonical k-mer (extension bits already cleared).  The words of the key are absorbed one mum
+// each; two further, independent mums of the state give the two halves of the hash, each the xor of a product's
+// halves (the high half of a product alone is far from uniform).  The high 32 bits pick the owner shard and the LDS
+// slot, the low 32 bits the two bucket levels.  Any deterministic function gives the same final set (F3).
 template <int NL>
 KC_HD uint64_t kc_hash(const uint64_t (&key)[NL]) {
-  uint64_t h = 0x9E3779B97F4A7C15ULL;
+  uint32_t a = 0x9E3779B9u, b = 0x85EBCA6Bu;
 #pragma unroll
-  for (int j = 0; j < NL; j++) h = kc_mix64(h ^ key[j]);
-  return h;
+  for (int j = 0; j < NL; j++) {
+    a ^= (uint32_t)key[j];
+    b ^= (uint32_t)(key[j] >> 32);
+    kc_mum32(a, b, 0x53c5ca59u, 0x74743c1bu);
+  }
+  uint32_t a2 = a, b2 = b;
+  kc_mum32(a, b, 0x53c5ca59u, 0x74743c1bu);
+  kc_mum32(a2, b2, 0xa0761d65u, 0xe7037ed1u);
+  return ((uint64_t)(a2 ^ b2) << 32) | (uint64_t)(a ^ b);
 }
 
 KC_HD uint32_t kc_owner_of_hash(uint64_t h, uint32_t rank_n) {

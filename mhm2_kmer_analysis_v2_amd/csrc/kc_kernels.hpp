@@ -26,9 +26,18 @@ constexpr int PPT = 16;                 // positions per thread
 constexpr int TILE = TPB * PPT;         // 4096 positions per workgroup
 constexpr int PRE = 32;                 // staged positions before the tile (left neighbour of its first k-mer)
 constexpr int POST = 192;               // staged positions after it: k+1 <= 128, + one word for the funnel, + slack
-constexpr int LSPAN = PRE + TILE + POST;  // 4320
-constexpr int NGROUP = LSPAN / 16;      // 270 sixteen-base groups
-constexpr int NWORD = LSPAN / 32;       // 135
+// geometry of a staged tile: THREADS threads share it, the k-mers starting at its SPAN positions are cut from it
+template <int THREADS_, int SPAN_>
+struct TileGeo {
+  static constexpr int THREADS = THREADS_;
+  static constexpr int SPAN = SPAN_;
+  static constexpr int LSPAN = PRE + SPAN_ + POST;                // staged positions
+  static constexpr int NGROUP = LSPAN / 16;                       // sixteen-base groups
+  static constexpr int NWORD = LSPAN / 32;
+  static constexpr int GPT = (NGROUP + THREADS_ - 1) / THREADS_;  // groups a thread stages
+  static_assert(LSPAN % 32 == 0, "staged span must be whole words");
+};
+using TileSmall = TileGeo<TPB, TILE>;  // the global-table kernel: 4320 staged positions, 270 groups, 2 per thread
 
 constexpr uint64_t KEY_EMPTY = ~0ULL;
 constexpr uint64_t KEY_BUSY = ~0ULL - 1;
@@ -36,7 +45,10 @@ constexpr uint64_t KEY_BUSY = ~0ULL - 1;
 enum { MODE_INSERT = 0, MODE_BIN = 1 };
 // input formats: ASCII bases + qualities; the reference's '_'-joined case-masked block; the reference's read
 // cache bytes (3-bit base | 5-bit quality << 3, src/packed_reads.cpp:99-126)
-enum { FMT_READS = 0, FMT_SEQBLOCK = 1, FMT_PACKED = 2 };
+// FMT_READS_UQ: FMT_READS whose quality array is not 16-byte co-aligned with the base array (its own
+// instantiation: the byte loads it needs would otherwise cost the common case registers)
+enum { FMT_READS = 0, FMT_SEQBLOCK = 1, FMT_PACKED = 2, FMT_READS_UQ = 3 };
+constexpr bool fmt_is_reads(int fmt) { return fmt == FMT_READS || fmt == FMT_READS_UQ; }
 
 // device-side counters, one u64 each (host mirror in kc_api)
 enum {
@@ -67,8 +79,7 @@ struct ExtractArgs {
   uint64_t nreads;
   uint64_t total;           // bytes of real data
   uint32_t align;           // real data starts at aligned coordinate `align` (0..15)
-  uint32_t quals_vector_ok; // quals can be loaded 16 bytes at a time at the same shift
-  uint64_t tile0;           // first tile of this launch
+  int64_t pos0;             // aligned coordinate where the first tile of this launch starts
   int k;
   int qual_cut;             // qual_offset + KC_QUAL_CUTOFF
   uint32_t rank_me, rank_n;
@@ -146,10 +157,11 @@ __device__ __forceinline__ void table_insert(const Table &t, const uint64_t (&re
 }
 
 // ---- tile staging --------------------------------------------------------------------------
+template <class G>
 struct alignas(16) TileLDS {
-  uint32_t codes[NGROUP];   // 2-bit codes; u64 word w = {codes[2w+1] (first 16 bases), codes[2w]}
-  uint16_t ok[NGROUP];      // bit i: base 16g+i may serve as an extension (high quality, ACGT)
-  uint32_t gap[NWORD + 1];  // bit lp: a read boundary lies between local positions lp-1 and lp
+  uint32_t codes[G::NGROUP];   // 2-bit codes; u64 word w = {codes[2w+1] (first 16 bases), codes[2w]}
+  uint16_t ok[G::NGROUP];      // bit i: base 16g+i may serve as an extension (high quality, ACGT)
+  uint32_t gap[G::NWORD + 1];  // bit lp: a read boundary lies between local positions lp-1 and lp
 };
 
 __device__ __forceinline__ uint32_t pack4(uint32_t v) {  // 4 ASCII bytes -> 4 codes, first byte highest
@@ -167,43 +179,93 @@ constexpr uint32_t BM_ACGT = (1u << 1) | (1u << 3) | (1u << 7) | (1u << 20);
 constexpr uint32_t BM_ACGTN = BM_ACGT | (1u << 14);
 __device__ __forceinline__ bool in_bitmap(uint32_t c, uint32_t bm) { return ((c & 0xC0u) == 0x40u) && ((bm >> (c & 31u)) & 1u); }
 
+// ---- sixteen bytes at a time -----------------------------------------------------------------------------------
+// Byte-parallel predicates: a result word carries its answer in bit 7 of every byte, the other bits are garbage
+// until the final gather.  nz7(x): bit 7 set where the byte of x is not zero.
+__device__ __forceinline__ uint32_t nz7(uint32_t x) { return ((x & 0x7F7F7F7Fu) + 0x7F7F7F7Fu) | x; }
+// S2/S5 for a group whose sixteen bytes are all real data: okm bit i = byte i may serve as an extension,
+// sepm bit i = byte i is a separator (FMT_SEQBLOCK), bad |= a byte outside the alphabet
+template <int FMT>
+__device__ __forceinline__ void encode_group_swar(const uint32_t (&bw)[4], const uint32_t (&qw)[4], uint32_t qual_cut, uint32_t &okm,
+                                                  uint32_t &sepm, bool &bad) {
+  // one word after the other, each folded into the running gathers at once (few values live at a time)
+  uint32_t badacc = 0, ok_lo = 0, ok_hi = 0, sp_lo = 0, sp_hi = 0;
+#pragma unroll
+  for (int j = 0; j < 4; j++) {
+    const uint32_t w = bw[j];
+    const uint32_t weight = (j & 1) ? 0x80402010u : 0x08040201u;  // byte i of the half-group -> bit i (times 0x80)
+    uint32_t ok, sp = 0;
+    if (FMT == FMT_PACKED) {
+      // base = low 3 bits (0-4), quality = high 5: quality >= 20 <=> byte >= 0xA0; base > 4 <=> bit2 & (bit1 | bit0)
+      const uint32_t x = w & ((w << 1) | (w << 2));  // bit 7: high quality, bit 2: bad base code
+      badacc |= x << 5;
+      ok = x & ~(w << 5);                            // high quality and base < 4
+    } else {
+      const uint32_t u = w & 0xDFDFDFDFu;  // upper case
+      const uint32_t not_acgt = nz7(u ^ 0x41414141u) & nz7(u ^ 0x43434343u) & nz7(u ^ 0x47474747u) & nz7(u ^ 0x54545454u);
+      const uint32_t not_n = nz7(u ^ 0x4E4E4E4Eu);
+      uint32_t hq;
+      if (fmt_is_reads(FMT)) {
+        const uint32_t q = qw[j];
+        hq = (((q & 0x7F7F7F7Fu) | 0x80808080u) - qual_cut * 0x01010101u) | q;  // S2: byte >= qual_cut (<= 128)
+        badacc |= not_acgt & not_n;
+      } else {
+        hq = ~(w << 2);                    // case carries the quality: bit 5 clear
+        const uint32_t not_sep = nz7(w ^ 0x5F5F5F5Fu);
+        sp = ~not_sep;
+        badacc |= not_acgt & not_n & not_sep;
+      }
+      ok = hq & ~not_acgt;
+    }
+    if (j < 2) {
+      ok_lo = __builtin_amdgcn_udot4(ok & 0x80808080u, weight, ok_lo, false);
+      if (FMT == FMT_SEQBLOCK) sp_lo = __builtin_amdgcn_udot4(sp & 0x80808080u, weight, sp_lo, false);
+    } else {
+      ok_hi = __builtin_amdgcn_udot4(ok & 0x80808080u, weight, ok_hi, false);
+      if (FMT == FMT_SEQBLOCK) sp_hi = __builtin_amdgcn_udot4(sp & 0x80808080u, weight, sp_hi, false);
+    }
+  }
+  okm = (ok_lo >> 7) | ((ok_hi >> 7) << 8);
+  if (FMT == FMT_SEQBLOCK) sepm = (sp_lo >> 7) | ((sp_hi >> 7) << 8);
+  if (badacc & 0x80808080u) bad = true;
+}
+
 // Staging a tile has two halves so that a kernel can keep the next tile's bytes in flight while it works on the
 // current one: tile_prefetch issues the global loads into registers (nothing waits on them), tile_encode turns
 // the registers into the LDS image.  Aligned coordinate x = byte index from the 16-byte aligned base address;
-// local position lp = x - (T0 - PRE).  Thread tid (0..TPB-1 of the TPB threads sharing the tile) owns the
-// 16-byte groups tid and tid + TPB.
+// local position lp = x - (T0 - PRE).  Thread tid (of the G::THREADS threads sharing the tile) owns the
+// 16-byte groups tid, tid + G::THREADS, ...
 // Barrier for data exchanged through LDS only: __syncthreads() would also drain the vector-memory counter, i.e.
 // wait for every global store and prefetch load this wave still has in flight.
 __device__ __forceinline__ void tile_barrier() { asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory"); }
 
-constexpr int GROUPS_PER_THREAD = (NGROUP + TPB - 1) / TPB;  // 2
-
+template <class G>
 struct TileRaw {
-  uint32_t bw[GROUPS_PER_THREAD][4];
-  uint32_t qw[GROUPS_PER_THREAD][4];
+  uint32_t bw[G::GPT][4];
+  uint32_t qw[G::GPT][4];
   uint64_t first_read;  // first read starting at or after the tile's first position
   uint64_t off;         // offsets[first_read + tid], or ~0 past the end
 };
 
-template <int FMT>
-__device__ __forceinline__ void tile_prefetch(TileRaw &R, const ExtractArgs &a, int64_t T0, int tid, uint64_t tile_first_read, bool active) {
+template <int FMT, class G>
+__device__ __forceinline__ void tile_prefetch(TileRaw<G> &R, const ExtractArgs &a, int64_t T0, int tid, uint64_t tile_first_read, bool active) {
   const int64_t lo = a.align, hi = (int64_t)a.align + (int64_t)a.total;  // real data is [lo, hi)
 #pragma unroll
-  for (int gi = 0; gi < GROUPS_PER_THREAD; gi++) {
+  for (int gi = 0; gi < G::GPT; gi++) {
 #pragma unroll
     for (int w = 0; w < 4; w++) {
       R.bw[gi][w] = 0;
       R.qw[gi][w] = 0;
     }
-    const int g = tid + gi * TPB;
+    const int g = tid + gi * G::THREADS;
     const int64_t X0 = T0 - PRE + 16 * g;
-    if (active && g < NGROUP && (X0 + 16 > lo) && (X0 < hi)) {
+    if (active && g < G::NGROUP && (X0 + 16 > lo) && (X0 < hi)) {
       // the 16-byte line holding the group is inside the allocation's aligned span whenever any
       // of its bytes is real data, so the vector load is safe; bytes outside [lo,hi) are masked when encoding
       const uint4 v = *reinterpret_cast<const uint4 *>(a.bases + X0);
       R.bw[gi][0] = v.x; R.bw[gi][1] = v.y; R.bw[gi][2] = v.z; R.bw[gi][3] = v.w;
-      if (FMT == FMT_READS) {
-        if (a.quals_vector_ok) {
+      if (fmt_is_reads(FMT)) {
+        if (FMT == FMT_READS) {
           const uint4 q = *reinterpret_cast<const uint4 *>(a.quals + X0);
           R.qw[gi][0] = q.x; R.qw[gi][1] = q.y; R.qw[gi][2] = q.z; R.qw[gi][3] = q.w;
         } else {
@@ -220,12 +282,24 @@ __device__ __forceinline__ void tile_prefetch(TileRaw &R, const ExtractArgs &a, 
   if (FMT != FMT_SEQBLOCK && active && tile_first_read + tid <= a.nreads) R.off = a.offsets[tile_first_read + tid];
 }
 
-template <int FMT>
-__device__ __forceinline__ void tile_encode(TileLDS &L, const TileRaw &R, const ExtractArgs &a, int64_t T0, uint64_t *ctrs, int tid,
+template <int FMT, class G>
+__device__ __forceinline__ void tile_encode(TileLDS<G> &L, const TileRaw<G> &R, const ExtractArgs &a, int64_t T0, uint64_t *ctrs, int tid,
                                             bool active) {
   // every thread of the workgroup reaches both barriers
-  for (int i = tid; i < NWORD + 1; i += TPB) L.gap[i] = 0;
+#ifdef KC_STAMPS
+  unsigned long long ts_ = __builtin_amdgcn_s_memtime();
+#define KC_ENC_STAMP(k)                                                              \
+  if (threadIdx.x == 0) {                                                            \
+    const unsigned long long tn_ = __builtin_amdgcn_s_memtime();                     \
+    atomicAdd((unsigned long long *)&ctrs[CTR_BIN0 + 40 + k], tn_ - ts_);            \
+    ts_ = tn_;                                                                       \
+  }
+#else
+#define KC_ENC_STAMP(k)
+#endif
+  for (int i = tid; i < G::NWORD + 1; i += G::THREADS) L.gap[i] = 0;
   tile_barrier();
+  KC_ENC_STAMP(0)
   if (!active) {
     tile_barrier();
     return;
@@ -233,9 +307,9 @@ __device__ __forceinline__ void tile_encode(TileLDS &L, const TileRaw &R, const 
   const int64_t lo = a.align, hi = (int64_t)a.align + (int64_t)a.total;
   bool bad = false;
 #pragma unroll
-  for (int gi = 0; gi < GROUPS_PER_THREAD; gi++) {
-    const int g = tid + gi * TPB;
-    if (g >= NGROUP) break;
+  for (int gi = 0; gi < G::GPT; gi++) {
+    const int g = tid + gi * G::THREADS;
+    if (g >= G::NGROUP) break;
     const int64_t X0 = T0 - PRE + 16 * g;
     const uint32_t(&bw)[4] = R.bw[gi];
     const uint32_t(&qw)[4] = R.qw[gi];
@@ -244,31 +318,49 @@ __device__ __forceinline__ void tile_encode(TileLDS &L, const TileRaw &R, const 
     uint32_t code = FMT == FMT_PACKED ? (pack4_cache(bw[0]) << 24) | (pack4_cache(bw[1]) << 16) | (pack4_cache(bw[2]) << 8) | pack4_cache(bw[3])
                                       : (pack4(bw[0]) << 24) | (pack4(bw[1]) << 16) | (pack4(bw[2]) << 8) | pack4(bw[3]);
     uint32_t okm = 0, sepm = 0;
+    if (full && (!fmt_is_reads(FMT) || a.qual_cut <= 128)) {
+      encode_group_swar<FMT>(bw, qw, (uint32_t)a.qual_cut, okm, sepm, bad);
+    } else {
+      // groups at the edges of the data: byte by byte, bytes outside [lo, hi) masked
 #pragma unroll
-    for (int i = 0; i < 16; i++) {
-      const uint32_t c = (bw[i >> 2] >> (8 * (i & 3))) & 0xFFu;
-      const bool real = full || (any && (X0 + i >= lo) && (X0 + i < hi));
-      bool hq;
-      if (FMT == FMT_PACKED) {
-        hq = (c >> 3) >= KC_QUAL_CUTOFF;                      // S2 on the stored quality (already relative to qual_offset)
-        if (real && (c & 7u) > 4u) bad = true;
-        if (real && hq && (c & 7u) < 4u) okm |= 1u << i;
-        continue;
+      for (int j = 0; j < 4; j++) {
+        uint32_t wb = bw[j], wq = qw[j];
+#pragma unroll 1
+        for (int i = 4 * j; i < 4 * j + 4; i++, wb >>= 8, wq >>= 8) {
+          const uint32_t c = wb & 0xFFu;
+          const bool real = full || (any && (X0 + i >= lo) && (X0 + i < hi));
+          bool hq;
+          if (FMT == FMT_PACKED) {
+            hq = (c >> 3) >= KC_QUAL_CUTOFF;                      // S2 on the stored quality (already relative to qual_offset)
+            if (real && (c & 7u) > 4u) bad = true;
+            if (real && hq && (c & 7u) < 4u) okm |= 1u << i;
+            continue;
+          }
+          if (fmt_is_reads(FMT)) {
+            const int q = (int)(wq & 0xFFu);
+            hq = q >= a.qual_cut;                                 // S2
+            if (real && !in_bitmap(c, BM_ACGTN)) bad = true;
+          } else {
+            hq = (c & 0x20u) == 0;                                // case carries the quality
+            const bool sep = (c == '_');
+            if (real && sep) sepm |= 1u << i;
+            if (real && !sep && !in_bitmap(c, BM_ACGTN)) bad = true;
+          }
+          if (real && hq && in_bitmap(c, BM_ACGT)) okm |= 1u << i;
+        }
       }
-      if (FMT == FMT_READS) {
-        const int q = (int)((qw[i >> 2] >> (8 * (i & 3))) & 0xFFu);
-        hq = q >= a.qual_cut;                                 // S2
-        if (real && !in_bitmap(c, BM_ACGTN)) bad = true;
-      } else {
-        hq = (c & 0x20u) == 0;                                // case carries the quality
-        const bool sep = (c == '_');
-        if (real && sep) sepm |= 1u << i;
-        if (real && !sep && !in_bitmap(c, BM_ACGTN)) bad = true;
-      }
-      if (real && hq && in_bitmap(c, BM_ACGT)) okm |= 1u << i;
     }
     L.codes[g ^ 1] = code;
     L.ok[g] = (uint16_t)okm;
+    if (!full) {
+      // positions outside the data count as read boundaries, so that no window can reach into them
+      uint32_t nonreal = 0xFFFFu;
+      if (any) {
+        const int i0 = (int)(lo > X0 ? lo - X0 : 0), i1 = (int)(hi - X0 < 16 ? hi - X0 : 16);
+        nonreal = ~(((1u << i1) - 1u) & ~((1u << i0) - 1u)) & 0xFFFFu;
+      }
+      atomicOr(&L.gap[g >> 1], nonreal << (16 * (g & 1)));
+    }
     if (FMT == FMT_SEQBLOCK && sepm) {
       // a separator at q kills every window [p-1, p+k] that contains q: gaps q and q+1
       uint64_t bits = ((uint64_t)sepm | ((uint64_t)sepm << 1)) << (16 * (g & 1));
@@ -276,12 +368,13 @@ __device__ __forceinline__ void tile_encode(TileLDS &L, const TileRaw &R, const 
       if (bits >> 32) atomicOr(&L.gap[(g >> 1) + 1], (uint32_t)(bits >> 32));
     }
   }
+  KC_ENC_STAMP(1)
   if (FMT != FMT_SEQBLOCK) {
     // boundaries from the read offsets (the end of the data is offsets[nreads]); the first one of this thread
-    // came with the prefetch, more only when a tile holds over TPB reads
-    const int64_t first = T0, last = T0 + TILE + a.k;  // gaps that any window of this tile can contain
+    // came with the prefetch, more only when a tile holds more reads than it has threads
+    const int64_t first = T0, last = T0 + G::SPAN + a.k;  // gaps that any window of this tile can contain
     uint64_t off = R.off;
-    for (uint64_t r = R.first_read + tid; r <= a.nreads; r += TPB) {
+    for (uint64_t r = R.first_read + tid; r <= a.nreads; r += G::THREADS) {
       if (r != R.first_read + tid) off = a.offsets[r];
       const int64_t s = (int64_t)off + lo;
       if (s > last) break;
@@ -294,28 +387,30 @@ __device__ __forceinline__ void tile_encode(TileLDS &L, const TileRaw &R, const 
     // start and end of the block are boundaries too
     if (tid == 0) {
       int64_t s0 = lo - (T0 - PRE), s1 = hi - (T0 - PRE);
-      if (s0 >= 0 && s0 < LSPAN) atomicOr(&L.gap[s0 >> 5], 1u << (s0 & 31));
-      if (s1 >= 0 && s1 < LSPAN) atomicOr(&L.gap[s1 >> 5], 1u << (s1 & 31));
+      if (s0 >= 0 && s0 < G::LSPAN) atomicOr(&L.gap[s0 >> 5], 1u << (s0 & 31));
+      if (s1 >= 0 && s1 < G::LSPAN) atomicOr(&L.gap[s1 >> 5], 1u << (s1 & 31));
     }
   }
   if (bad) ctrs[CTR_BAD_BASE] = 1;
+  KC_ENC_STAMP(2)
   tile_barrier();
+  KC_ENC_STAMP(3)
 }
 
 // both halves back to back (kernels that do not pipeline their tiles)
-template <int FMT>
-__device__ __forceinline__ void stage_tile(TileLDS &L, const ExtractArgs &a, int64_t T0, uint64_t *ctrs, int tid, uint64_t tile_first_read,
+template <int FMT, class G>
+__device__ __forceinline__ void stage_tile(TileLDS<G> &L, const ExtractArgs &a, int64_t T0, uint64_t *ctrs, int tid, uint64_t tile_first_read,
                                            bool active) {
-  TileRaw R;
-  tile_prefetch<FMT>(R, a, T0, tid, tile_first_read, active);
-  tile_encode<FMT>(L, R, a, T0, ctrs, tid, active);
+  TileRaw<G> R;
+  tile_prefetch<FMT, G>(R, a, T0, tid, tile_first_read, active);
+  tile_encode<FMT, G>(L, R, a, T0, ctrs, tid, active);
 }
 
 // Cut the k-mer that starts at local position lp out of the staged tile.  Returns false if the
 // window [lp-1, lp+k] crosses a read boundary (S1, S5).  rec = canonical k-mer (S3, S4) with the
 // extension codes (S5) in the low 6 bits of its last word; h = hash of the bare k-mer.
-template <int NL>
-__device__ __forceinline__ bool tile_kmer(const TileLDS &L, int lp, int k, uint64_t (&rec)[NL], uint64_t &h, uint32_t rank_n = 1,
+template <int NL, class TL>
+__device__ __forceinline__ bool tile_kmer(const TL &L, int lp, int k, uint64_t (&rec)[NL], uint64_t &h, uint32_t rank_n = 1,
                                           uint32_t reference_owner = 0, uint32_t *owner = nullptr) {
   {  // any boundary among gaps lp .. lp+k ?
     int rem = k + 1, w = lp >> 5, s = lp & 31;
@@ -364,11 +459,106 @@ __device__ __forceinline__ bool tile_kmer(const TileLDS &L, int lp, int k, uint6
   return true;
 }
 
+// Rolling form of tile_kmer for a run of consecutive positions lp0, lp0+1, ...: the first k-mer and its reverse
+// complement are cut out once, every further one costs a 2-bit shift of both; the boundary test becomes "no boundary
+// gap at or after the position among those seen so far".  Same results as tile_kmer position by position.
+template <int NL>
+struct KmerRun {
+  uint64_t f[NL], r[NL];  // forward k-mer and reverse complement at the current position
+  uint64_t nextb;         // bases lp+k, lp+k+1, ...: 2 bits each, the first one highest
+  uint32_t okl, okr;      // bit j: base lp0-1+j / base lp0+k+j may serve as an extension
+  uint32_t gin;           // bit j: read boundary at gap lp0+k+1+j
+  uint32_t lc;            // code of base lp-1
+  int lastgap;            // highest boundary gap <= lp+k (-1: none)
+};
+
+template <int NL, class TL>
+__device__ __forceinline__ void run_begin(KmerRun<NL> &s, const TL &L, int lp0, int k) {
+  const uint64_t *W = reinterpret_cast<const uint64_t *>(L.codes);
+  {
+    const int q = lp0 >> 5, sh = 2 * (lp0 & 31);
+#pragma unroll
+    for (int j = 0; j < NL; j++) {
+      const uint64_t hi = W[q + j], lo = W[q + j + 1];
+      s.f[j] = (sh ? ((hi << sh) | (lo >> (64 - sh))) : hi) & kc_word_mask(k, j);
+    }
+  }
+  kc_revcomp<NL>(s.f, k, s.r);
+  const int pl = lp0 - 1, pr = lp0 + k;
+  {
+    const int q = pr >> 5, sh = 2 * (pr & 31);
+    const uint64_t hi = W[q], lo = W[q + 1];
+    s.nextb = sh ? ((hi << sh) | (lo >> (64 - sh))) : hi;
+  }
+  s.lc = (uint32_t)(W[pl >> 5] >> (62 - 2 * (pl & 31))) & 3u;
+  s.okl = ((uint32_t)L.ok[pl >> 4] | ((uint32_t)L.ok[(pl >> 4) + 1] << 16)) >> (pl & 15);
+  s.okr = ((uint32_t)L.ok[pr >> 4] | ((uint32_t)L.ok[(pr >> 4) + 1] << 16)) >> (pr & 15);
+  {
+    const int a = pr + 1, w = a >> 5, sh = a & 31;
+    const uint32_t g0 = L.gap[w], g1 = L.gap[w + 1];
+    s.gin = sh ? ((g0 >> sh) | (g1 << (32 - sh))) : g0;
+  }
+  int last = -1;
+  const int w0 = lp0 >> 5, w1 = pr >> 5;
+  for (int w = w0; w <= w1; w++) {
+    uint32_t bits = L.gap[w];
+    if (w == w0) bits &= ~0u << (lp0 & 31);
+    if (w == w1 && (pr & 31) < 31) bits &= (2u << (pr & 31)) - 1u;
+    if (bits) last = 32 * w + 31 - __clz(bits);
+  }
+  s.lastgap = last;
+}
+
+// the k-mer at position lp0 + j (the run has been advanced j times); same outputs as tile_kmer
+template <int NL>
+__device__ __forceinline__ bool run_kmer(const KmerRun<NL> &s, int j, int lp0, int k, uint64_t (&rec)[NL], uint64_t &h, uint32_t rank_n = 1,
+                                         uint32_t reference_owner = 0, uint32_t *owner = nullptr) {
+  const uint32_t c = (uint32_t)(s.nextb >> 62);
+  uint32_t le = ((s.okl >> j) & 1u) ? s.lc : KC_EXT_NONE;
+  uint32_t re = ((s.okr >> j) & 1u) ? c : KC_EXT_NONE;
+  if (owner) *owner = 0;
+  if (owner && rank_n > 1 && reference_owner) *owner = kc_reference_owner<NL>(s.f, s.r, k, rank_n);
+  uint64_t f[NL];
+  const bool swap = kc_less<NL>(s.r, s.f);  // strict: a palindrome keeps the forward extensions
+#pragma unroll
+  for (int w = 0; w < NL; w++) f[w] = swap ? s.r[w] : s.f[w];
+  const uint32_t nl = (re == KC_EXT_NONE) ? KC_EXT_NONE : 3u - re;
+  const uint32_t nr = (le == KC_EXT_NONE) ? KC_EXT_NONE : 3u - le;
+  le = swap ? nl : le;
+  re = swap ? nr : re;
+  h = kc_hash<NL>(f);
+  if (owner && rank_n > 1 && !reference_owner) *owner = kc_owner_of_hash(h, rank_n);
+#pragma unroll
+  for (int w = 0; w < NL; w++) rec[w] = f[w];
+  rec[NL - 1] |= (uint64_t)(le | (re << 3));
+  return s.lastgap < lp0 + j;
+}
+
+// from position lp0 + j to lp0 + j + 1
+template <int NL>
+__device__ __forceinline__ void run_advance(KmerRun<NL> &s, int j, int lp0, int k) {
+  const uint64_t c = s.nextb >> 62;
+  s.nextb <<= 2;
+  s.lc = (uint32_t)(s.f[0] >> 62);
+  const int wi = (k - 1) >> 5, bit = 62 - 2 * ((k - 1) & 31);  // where the last base of a k-mer sits
+#pragma unroll
+  for (int w = 0; w < NL; w++) {
+    s.f[w] = (s.f[w] << 2) | (w + 1 < NL ? s.f[w + 1] >> 62 : 0ULL);
+    if (w == wi) s.f[w] |= c << bit;
+  }
+#pragma unroll
+  for (int w = NL - 1; w >= 0; w--) {
+    s.r[w] = (s.r[w] >> 2) | (w > 0 ? s.r[w - 1] << 62 : (3ULL - c) << 62);
+    s.r[w] &= kc_word_mask(k, w);
+  }
+  if ((s.gin >> j) & 1u) s.lastgap = lp0 + j + k + 1;
+}
+
 template <int NL, int FMT>
 __global__ __launch_bounds__(TPB) void kc_extract_kernel(ExtractArgs a, Table t, uint64_t *ctrs) {
-  __shared__ TileLDS L;
-  const int64_t T0 = (int64_t)(a.tile0 + blockIdx.x) * TILE;
-  stage_tile<FMT>(L, a, T0, ctrs, threadIdx.x, FMT != FMT_SEQBLOCK ? a.tile_first[blockIdx.x] : 0, true);
+  __shared__ TileLDS<TileSmall> L;
+  const int64_t T0 = a.pos0 + (int64_t)blockIdx.x * TILE;
+  stage_tile<FMT, TileSmall>(L, a, T0, ctrs, threadIdx.x, FMT != FMT_SEQBLOCK ? a.tile_first[blockIdx.x] : 0, true);
   const int64_t lo = a.align, hi = (int64_t)a.align + (int64_t)a.total;
   uint32_t n_ins = 0;
 #pragma unroll 1
@@ -405,11 +595,11 @@ __global__ __launch_bounds__(TPB) void kc_insert_records_kernel(const uint64_t *
 }
 
 // first read whose start lies at or after each tile's first position (lower bound on the offsets)
-__global__ void kc_tile_first_kernel(const uint64_t *offsets, uint64_t nreads, uint32_t align, uint64_t tile0, uint64_t ntiles,
+__global__ void kc_tile_first_kernel(const uint64_t *offsets, uint64_t nreads, uint32_t align, int64_t pos0, uint32_t span, uint64_t ntiles,
                                      uint64_t *tile_first) {
   uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
   if (i >= ntiles) return;
-  int64_t T0 = (int64_t)(tile0 + i) * TILE - (int64_t)align;  // in offset coordinates
+  int64_t T0 = pos0 + (int64_t)i * span - (int64_t)align;  // in offset coordinates
   uint64_t lo = 0, hi = nreads + 1;                            // offsets has nreads+1 entries
   while (lo < hi) {
     uint64_t mid = (lo + hi) >> 1;

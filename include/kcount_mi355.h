@@ -206,7 +206,8 @@ int kc_get_stats(kc_ctx *ctx, kc_stats *out);
  * (forcing the overflow paths with tiny capacities) and tuning runs; call right after
  * kc_create / kc_reset, before the first submit. */
 typedef struct kc_tuning {
-  uint32_t mode;          /* 0 auto (bucketed), 1 global-table path only */
+  uint32_t mode;          /* 0 auto (bucketed; compact records where k and the geometry allow), 1 global-table path only,
+                             2 bucketed with wide records only */
   uint32_t writers;       /* level-1 writer workgroups (<= 512) */
   uint32_t p1, p2;        /* fan-out of level 1 / level 2: 1..1024 each */
   uint32_t slots;         /* LDS slots per region */

@@ -385,7 +385,7 @@ extern "C" int kc_reset(kc_ctx *c, int new_k) {
   if (st) return st;
   HIPCHK(hipSetDevice(c->cfg.device));
   HIPCHK(hipStreamSynchronize(c->stream));
-  const int old_nl = c->nl;
+  const int old_nl = c->nl, old_k = c->k;
   if (kc_num_longs(new_k) != old_nl) free_results(c);  // else the result arrays are reused by the next finalize
   c->out_n = 0;
   c->k = new_k;
@@ -402,9 +402,10 @@ extern "C" int kc_reset(kc_ctx *c, int new_k) {
   c->finalized = false;
   c->num_reads = c->num_bases = 0;
   c->purged = c->sum_counts = c->unique_at_finalize = 0;
-  // bucketed path: keep the arrays when the record width is unchanged, else choose the geometry again
+  // bucketed path: keep the arrays when the record width is unchanged, else choose the geometry again (so does a
+  // new k among the one-word ones: whether the records are compact, and how, depends on k)
   if (c->bk_ready) {
-    if (c->nl != old_nl) {
+    if (c->nl != old_nl || (c->nl == 1 && new_k != old_k)) {
       bk_free(c);
     } else {
       const size_t R = (size_t)c->gm.P1 * c->gm.P2;
@@ -468,6 +469,31 @@ static int bk_init(kc_ctx *c) {
   // multiply-shift), level 1 the smaller one because it holds fewer records per round
   g.P1 = t.p1 ? t.p1 : (uint32_t)std::max<double>(1.0, floor(sqrt((double)regions_needed)));
   g.P2 = t.p2 ? t.p2 : (uint32_t)((regions_needed + g.P1 - 1) / g.P1);
+  // Compact records (Geom::cp): one-word k-mers with k <= 23 whose regions imply at least 2k - 26 bits of the mixed
+  // k-mer.  The fan-outs must be powers of two, so an automatic choice is rounded up to the next such pair; fan-outs
+  // set by the caller are used as they are and decide by themselves.  tuning.mode 2 keeps the wide records.
+  if (c->nl == 1 && c->k <= KC_COMPACT_MAX_K && t.mode != 2) {
+    uint32_t la = 0, lb = 0;
+    if (t.p1 || t.p2) {
+      la = ilog2(g.P1);
+      lb = ilog2(g.P2);
+    } else {
+      const uint32_t lr = std::min<uint32_t>(20, ilog2(regions_needed));  // 2^lr >= regions_needed
+      la = lr / 2;
+      lb = lr - la;
+      if (2u * (uint32_t)c->k + 6u <= 32u + lr && la >= 1) {
+        g.P1 = 1u << la;
+        g.P2 = 1u << lb;
+      }
+    }
+    if (g.P1 == (1u << la) && g.P2 == (1u << lb) && la >= 1 && lb >= 1 && 2u * (uint32_t)c->k + 6u <= 32u + la + lb &&
+        2u * (uint32_t)c->k > la + lb) {
+      g.cp = 1;
+      g.la = la;
+      g.lb = lb;
+      g.k2 = 2u * (uint32_t)c->k;
+    }
+  }
   if (g.P1 < 1 || g.P2 < 1 || g.P1 > PMAX || g.P2 > PMAX) return KC_ERR_INVALID_ARG;
   // one writer per CU, but never so many that a writer's share of the buffer is below a few rounds of records
   g.G = t.writers ? std::min<uint32_t>(t.writers, GMAX)
@@ -491,7 +517,7 @@ static int bk_init(kc_ctx *c) {
   b.ovf1_cap = b.ovf2_cap = t.ovf_capacity ? t.ovf_capacity : bcap / 16 + 4096;
   const size_t w = (size_t)c->nl * 8;
   const size_t nseg = (size_t)g.G * g.P1;
-  const size_t rec1_bytes = (size_t)g.G * g.A1 * CH1 * w, rec2_bytes = (size_t)g.A2 * CH2 * w;
+  const size_t rec1_bytes = (size_t)g.G * g.A1 * CH1 * w, rec2_bytes = (size_t)g.A2 * CH2 * (g.cp ? 4 : w);
   HIPCHK(hipMalloc((void **)&b.rec1, rec1_bytes));
   HIPCHK(hipMalloc((void **)&b.chain1, nseg * g.L1MAX * 4));
   HIPCHK(hipMalloc((void **)&b.cnt1, nseg * 4));
@@ -535,9 +561,12 @@ template <int NL> static size_t lds_l1_reads() {
 template <int NL> static size_t lds_l1_records() { return ((sizeof(L1RLDS) + 15) & ~size_t(15)) + Rnd<NL>::STAGE; }
 template <int NL> static size_t lds_l2() { return ((sizeof(L2LDS) + 15) & ~size_t(15)) + Rnd<NL>::STAGE; }
 
+// compact records are a property of the geometry (bk_init) and only exist for one-word k-mers
+template <int NL> static bool use_cp(const kc_ctx *c) { return NL == 1 && c->gm.cp != 0; }
+
 template <int NL, int FMT>
 static int launch_l1_reads_t(kc_ctx *c, const ExtractArgs &a, uint64_t nsuper) {
-  auto kern = kc_l1_reads_kernel<NL, FMT>;
+  auto kern = use_cp<NL>(c) ? kc_l1_reads_kernel<NL, FMT, NL == 1> : kc_l1_reads_kernel<NL, FMT, false>;
   int rc = set_dyn_lds(kern, lds_l1_reads<NL>());
   if (rc) return rc;
   const unsigned grid = (unsigned)std::min<uint64_t>(c->gm.G, nsuper);
@@ -626,7 +655,7 @@ static int launch_bin_reads(kc_ctx *c, const ExtractArgs &a, uint64_t ntiles, in
 
 template <int NL>
 static int launch_l1_records_t(kc_ctx *c, const uint64_t *recs, uint64_t n) {
-  auto kern = kc_l1_records_kernel<NL>;
+  auto kern = use_cp<NL>(c) ? kc_l1_records_kernel<NL, NL == 1> : kc_l1_records_kernel<NL, false>;
   int rc = set_dyn_lds(kern, lds_l1_records<NL>());
   if (rc) return rc;
   const uint64_t per_round = (uint64_t)WGB * Rnd<NL>::RPOS;
@@ -641,7 +670,8 @@ template <int NL>
 static int bk_drain_t(kc_ctx *c) {
   {
     KernelTimer kt(c, KT_FALLBACK);
-    hipLaunchKernelGGL(kc_l1_to_table_kernel<NL>, dim3((unsigned)std::min<size_t>((size_t)c->gm.G * c->gm.P1, 65536)), dim3(TPB), 0, c->stream,
+    auto kern = use_cp<NL>(c) ? kc_l1_to_table_kernel<NL, NL == 1> : kc_l1_to_table_kernel<NL, false>;
+    hipLaunchKernelGGL(kern, dim3((unsigned)std::min<size_t>((size_t)c->gm.G * c->gm.P1, 65536)), dim3(TPB), 0, c->stream,
                        c->gm, c->bb, c->table, c->d_ctrs);
   }
   const uint64_t n1 = std::min<uint64_t>(c->h_cb[CB_OVF1], c->bb.ovf1_cap);
@@ -680,7 +710,7 @@ static int bk_drain_to_table(kc_ctx *c) {
   return KC_OK;
 }
 
-static bool bk_active(const kc_ctx *c) { return c->tuning.mode == 0 && !c->table_mode; }
+static bool bk_active(const kc_ctx *c) { return c->tuning.mode != 1 && !c->table_mode; }
 
 // ---- extraction launches -----------------------------------------------------------------------
 template <int NL, int FMT>
@@ -1085,7 +1115,7 @@ static int table_finalize_append(kc_ctx *c) {
 // ---- bucketed path: regions, counting, flagged regions ------------------------------------------
 template <int NL>
 static int bk_level2_t(kc_ctx *c) {
-  auto kern = kc_l2_split_kernel<NL>;
+  auto kern = use_cp<NL>(c) ? kc_l2_split_kernel<NL, NL == 1> : kc_l2_split_kernel<NL, false>;
   int rc = set_dyn_lds(kern, lds_l2<NL>());
   if (rc) return rc;
   hipLaunchKernelGGL(kc_bucket_prefix_kernel, dim3(1), dim3(WGB), 0, c->stream, c->gm, c->bb, c->d_cb);
@@ -1105,7 +1135,8 @@ static int bk_level2_t(kc_ctx *c) {
 #endif
   const uint64_t n1 = std::min<uint64_t>(c->h_cb[CB_OVF1], c->bb.ovf1_cap);
   if (n1) {
-    hipLaunchKernelGGL(kc_ovf1_to_regions_kernel<NL>, dim3((unsigned)((n1 + 255) / 256)), dim3(256), 0, c->stream, c->gm, c->bb, n1, c->d_cb);
+    auto okern = use_cp<NL>(c) ? kc_ovf1_to_regions_kernel<NL, NL == 1> : kc_ovf1_to_regions_kernel<NL, false>;
+    hipLaunchKernelGGL(okern, dim3((unsigned)((n1 + 255) / 256)), dim3(256), 0, c->stream, c->gm, c->bb, n1, c->d_cb);
     c->num_gpu_calls++;
     HIPCHK(hipGetLastError());
   }
@@ -1144,7 +1175,7 @@ static int bk_build_regions(kc_ctx *c) {
 
 template <int NL, bool DUMP>
 static int bk_count_t(kc_ctx *c, const OutBufs &ob) {
-  auto kern = kc_count_kernel<NL, DUMP>;
+  auto kern = use_cp<NL>(c) ? kc_count_kernel<NL, DUMP, NL == 1> : kc_count_kernel<NL, DUMP, false>;
   const size_t lds = CountLDS<NL>::bytes(c->gm.S);
   int rc = set_dyn_lds(kern, lds);
   if (rc) return rc;
@@ -1184,7 +1215,8 @@ template <int NL>
 static void launch_flagged_to_table(kc_ctx *c) {
   const uint64_t R = (uint64_t)c->gm.P1 * c->gm.P2;
   KernelTimer kt(c, KT_FALLBACK);
-  hipLaunchKernelGGL(kc_flagged_to_table_kernel<NL>, dim3((unsigned)std::min<uint64_t>(R, 65536)), dim3(TPB), 0, c->stream, c->gm, c->bb,
+  auto kern = use_cp<NL>(c) ? kc_flagged_to_table_kernel<NL, NL == 1> : kc_flagged_to_table_kernel<NL, false>;
+  hipLaunchKernelGGL(kern, dim3((unsigned)std::min<uint64_t>(R, 65536)), dim3(TPB), 0, c->stream, c->gm, c->bb,
                      c->table, c->d_ctrs);
 }
 
@@ -1431,7 +1463,7 @@ extern "C" int kc_get_stats(kc_ctx *c, kc_stats *o) {
 extern "C" int kc_set_tuning(kc_ctx *c, const kc_tuning *t) {
   if (!c || !t) return KC_ERR_INVALID_ARG;
   if (c->started) return KC_ERR_STATE;
-  if (t->mode > 1) return KC_ERR_INVALID_ARG;
+  if (t->mode > 2) return KC_ERR_INVALID_ARG;
   auto pow2_or_zero = [](uint32_t v) { return (v & (v - 1)) == 0; };
   if (!pow2_or_zero(t->chunk1) || !pow2_or_zero(t->chunk2) || t->p1 > PMAX || t->p2 > PMAX || t->writers > GMAX)
     return KC_ERR_INVALID_ARG;

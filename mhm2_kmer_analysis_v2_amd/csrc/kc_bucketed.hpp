@@ -55,6 +55,12 @@ struct Geom {
   uint32_t L1MAX, L2MAX;       // longest chain of a (writer,bucket) segment / of a region, in chunks
   uint32_t A1;                 // chunks in each writer's arena
   uint32_t A2;                 // chunks in the level-2 arena (all buckets)
+  // compact records (one-word k-mers with k <= KC_COMPACT_MAX_K, both fan-outs powers of two): the k-mer travels as
+  // its invertible mix (kc_feistel_fwd), the top la bits of which are the bucket, the next lb the region's index in
+  // the bucket and the low bits the probe start; level 2 then stores only what the region does not imply, in 32 bits
+  uint32_t cp;                 // 0: records carry the k-mer itself, buckets come from its hash
+  uint32_t la, lb;             // log2 P1, log2 P2
+  uint32_t k2;                 // 2k: bits of the mixed k-mer
 };
 
 struct BucketBufs {
@@ -84,6 +90,29 @@ __device__ __forceinline__ uint32_t hash_b1(uint64_t h, const Geom &g) { return 
 __device__ __forceinline__ uint32_t hash_b2(uint64_t h, const Geom &g) { return ((((uint32_t)h >> 16) & 0xFFFFu) * g.P2) >> 16; }
 __device__ __forceinline__ uint32_t hash_slot(uint64_t h, uint32_t S) {  // S is a power of two <= 4096
   return (uint32_t)(h >> 32) & (S - 1u);
+}
+
+// compact records: rec = mix << (64 - k2) | extension codes
+__device__ __forceinline__ uint64_t cp_mix_rec(uint64_t keyrec, const Geom &g) {  // k-mer record -> mixed record
+  const uint32_t sh = 64u - g.k2;
+  return (kc_feistel_fwd(keyrec >> sh, (int)(g.k2 >> 1)) << sh) | (keyrec & KC_EXT_MASK);
+}
+__device__ __forceinline__ uint64_t cp_unmix_rec(uint64_t mixrec, const Geom &g) {
+  const uint32_t sh = 64u - g.k2;
+  return (kc_feistel_inv(mixrec >> sh, (int)(g.k2 >> 1)) << sh) | (mixrec & KC_EXT_MASK);
+}
+__device__ __forceinline__ uint32_t cp_b1(uint64_t rec, const Geom &g) { return (uint32_t)(rec >> (64u - g.la)); }
+__device__ __forceinline__ uint32_t cp_b2(uint64_t rec, const Geom &g) { return (uint32_t)(rec >> (64u - g.la - g.lb)) & (g.P2 - 1u); }
+// what a region does not imply: the low bits of the mix, above the six extension bits
+__device__ __forceinline__ uint32_t cp_pack32(uint64_t rec, const Geom &g) {
+  const uint32_t rb = g.k2 - g.la - g.lb;
+  return (((uint32_t)(rec >> (64u - g.k2)) & ((1u << rb) - 1u)) << 6) | ((uint32_t)rec & (uint32_t)KC_EXT_MASK);
+}
+// back to the k-mer record from a region and its 32-bit record
+__device__ __forceinline__ uint64_t cp_unpack_rec(uint32_t rec32, size_t region, const Geom &g) {
+  const uint32_t rb = g.k2 - g.la - g.lb;
+  const uint64_t mix = ((uint64_t)region << rb) | (uint64_t)(rec32 >> 6);
+  return (kc_feistel_inv(mix, (int)(g.k2 >> 1)) << (64u - g.k2)) | (uint64_t)(rec32 & (uint32_t)KC_EXT_MASK);
 }
 
 template <int NL>
@@ -159,7 +188,7 @@ struct ChainDest {
   uint64_t *stamps;                 // diagnostic builds: cb + 8
   unsigned long long *tprev;        // thread 0's last stamp
 #endif
-  uint64_t *arena;      // chunk id c starts at arena + (c << log2CH) * NL
+  uint64_t *arena;      // chunk id c starts at record (c << log2CH) of the arena
   uint32_t *chain;      // destination b's chain: chain[b*LMAX + i]
   uint32_t log2CH, LMAX;
   uint32_t arena_cap;   // chunks this owner may take
@@ -174,11 +203,12 @@ struct ChainState {
 
 // Phase 2-4 of a round: scan, reserve, scatter to LDS, copy out.  The caller has already bumped
 // hist[buf] with LDS atomics (bucket | rank<<10 in br[], ~0 for "no record") and hit a barrier.
-//   bucket_of(hash) recomputes a record's bucket during copy-out; overflow(b, rec) takes what found no room
-template <int NL, int R, class BucketFn, class OvfFn>
+//   bucket_of(rec) recomputes a record's bucket during copy-out; overflow(b, rec) takes what found no room;
+//   store(i, rec) writes a record to position i (in records) of the destination arena
+template <int NL, int R, class BucketFn, class OvfFn, class StoreFn>
 __device__ __forceinline__ void split_round(SplitLDS &L, uint64_t *sorted, uint16_t *sbucket, int buf, uint32_t P,
                                             const uint64_t (&rec)[R][NL], const uint32_t (&br)[R], const ChainDest &D, ChainState &st,
-                                            BucketFn bucket_of, OvfFn overflow) {
+                                            BucketFn bucket_of, OvfFn overflow, StoreFn store) {
   // sbucket: optional LDS array parallel to `sorted` that remembers each staged record's bucket, so that the copy-out
   // need not hash the record again (null where the LDS has no room for it)
   const int tid = threadIdx.x;
@@ -249,7 +279,7 @@ __device__ __forceinline__ void split_round(SplitLDS &L, uint64_t *sorted, uint1
       }
     } else {
 #pragma unroll
-      for (int u = 0; u < U; u++) b[u] = bucket_of(rec_hash<NL>(r[u]));
+      for (int u = 0; u < U; u++) b[u] = bucket_of(r[u]);
     }
 #pragma unroll
     for (int u = 0; u < U; u++) {
@@ -260,9 +290,7 @@ __device__ __forceinline__ void split_round(SplitLDS &L, uint64_t *sorted, uint1
         const uint32_t db = L.dbase[b[u]], p = db + j, ci = p >> D.log2CH;
         // the run starts inside the chain's old last chunk (c0) unless it starts chunk-aligned; later chunks are new
         const uint32_t cid = ((db & CHm) && ci == (db >> D.log2CH)) ? L.c0[b[u]] : L.nb[b[u]] + ci;
-        uint64_t *d = D.arena + (((size_t)cid << D.log2CH) + (p & CHm)) * NL;
-#pragma unroll
-        for (int w = 0; w < NL; w++) d[w] = r[u][w];
+        store(((size_t)cid << D.log2CH) + (p & CHm), r[u]);
       } else {
         overflow(b[u], r[u]);
       }
@@ -271,6 +299,13 @@ __device__ __forceinline__ void split_round(SplitLDS &L, uint64_t *sorted, uint1
   KC_SPLIT_STAMP(4)  // copy-out
   // no barrier here: the next round only touches the other histogram buffer and registers until its own first
   // barrier, which every wave reaches after finishing this copy-out
+}
+
+// the plain store of split_round: NL words per record
+template <int NL>
+__device__ __forceinline__ void store_words(uint64_t *arena, size_t i, const uint64_t (&r)[NL]) {
+#pragma unroll
+  for (int w = 0; w < NL; w++) arena[i * NL + w] = r[w];
 }
 
 // load the persistent state of this owner's P chains (before its first round)
@@ -314,18 +349,19 @@ __device__ __forceinline__ ChainDest l1_dest(const Geom &gm, const BucketBufs &b
   return D;
 }
 
-template <int NL>
-__device__ __forceinline__ void l1_overflow(const BucketBufs &bb, uint64_t *cb, const uint64_t (&r)[NL]) {
+// the overflow lists always hold k-mer records (the global-table kernels read them), never mixed ones
+template <int NL, bool CP>
+__device__ __forceinline__ void l1_overflow(const Geom &gm, const BucketBufs &bb, uint64_t *cb, const uint64_t (&r)[NL]) {
   const uint64_t o = atomicAdd((unsigned long long *)&cb[CB_OVF1], 1ULL);
   if (o < bb.ovf1_cap) {
 #pragma unroll
-    for (int w = 0; w < NL; w++) bb.ovf1[o * NL + w] = r[w];
+    for (int w = 0; w < NL; w++) bb.ovf1[o * NL + w] = (CP && w == 0) ? cp_unmix_rec(r[w], gm) : r[w];
   } else {
     cb[CB_FATAL] = 1;
   }
 }
 
-template <int NL, int FMT>
+template <int NL, int FMT, bool CP>
 __global__ __launch_bounds__(WGB) void kc_l1_reads_kernel(ExtractArgs a, Geom gm, BucketBufs bb, uint64_t nsuper, uint32_t rot,
                                                           uint64_t *ctrs, uint64_t *cb) {
   extern __shared__ __align__(16) uint8_t smem[];
@@ -377,11 +413,19 @@ __global__ __launch_bounds__(WGB) void kc_l1_reads_kernel(ExtractArgs a, Geom gm
       for (int j = 0; j < RPOS; j++) {
         uint64_t h = 0;
         uint32_t owner = 0;
-        bool valid = run_kmer<NL>(run, j, lp0, a.k, rec[j], h, a.rank_n, a.reference_owner, &owner) && active;
+        bool valid = run_kmer<NL, !CP>(run, j, lp0, a.k, rec[j], h, a.rank_n, a.reference_owner, &owner) && active;
+        if (CP && a.rank_n > 1 && !a.reference_owner) {
+          uint64_t key[NL];
+#pragma unroll
+          for (int w = 0; w < NL; w++) key[w] = rec[j][w];
+          key[NL - 1] &= ~KC_EXT_MASK;
+          owner = kc_owner_of_hash(kc_hash<NL>(key), a.rank_n);
+        }
         if (a.rank_n > 1) valid = valid && owner == a.rank_me;
+        if (CP) rec[j][0] = cp_mix_rec(rec[j][0], gm);
         br[j] = ~0u;
         if (valid) {
-          const uint32_t b = hash_b1(h, gm);
+          const uint32_t b = CP ? cp_b1(rec[j][0], gm) : hash_b1(h, gm);
           const uint32_t rank = atomicAdd(&L.sp.hist[buf][b], 1u);
           br[j] = b | (rank << 10);
           n_ins++;
@@ -391,8 +435,10 @@ __global__ __launch_bounds__(WGB) void kc_l1_reads_kernel(ExtractArgs a, Geom gm
       KC_SPLIT_STAMP(0)  // cut the k-mers out of the super-tile, histogram
       lds_barrier();
       split_round<NL, RPOS>(
-          L.sp, sorted, sbucket, buf, P1, rec, br, D, cst, [&](uint64_t h) { return hash_b1(h, gm); },
-          [&](uint32_t, const uint64_t (&r)[NL]) { l1_overflow<NL>(bb, cb, r); });
+          L.sp, sorted, sbucket, buf, P1, rec, br, D, cst,
+          [&](const uint64_t (&r)[NL]) { return CP ? cp_b1(r[0], gm) : hash_b1(rec_hash<NL>(r), gm); },
+          [&](uint32_t, const uint64_t (&r)[NL]) { l1_overflow<NL, CP>(gm, bb, cb, r); },
+          [&](size_t i, const uint64_t (&r)[NL]) { store_words<NL>(D.arena, i, r); });
       buf ^= 1;
     }
   }
@@ -526,7 +572,7 @@ struct L1RLDS {
   SplitLDS sp;
 };
 
-template <int NL>
+template <int NL, bool CP>
 __global__ __launch_bounds__(WGB) void kc_l1_records_kernel(const uint64_t *recs, uint64_t n, Geom gm, BucketBufs bb, uint32_t rot,
                                                             uint64_t *ctrs, uint64_t *cb) {
   extern __shared__ __align__(16) uint8_t smem[];
@@ -552,7 +598,8 @@ __global__ __launch_bounds__(WGB) void kc_l1_records_kernel(const uint64_t *recs
       if (i < n) {
 #pragma unroll
         for (int w = 0; w < NL; w++) rec[j][w] = recs[i * NL + w];
-        const uint32_t b = hash_b1(rec_hash<NL>(rec[j]), gm);
+        if (CP) rec[j][0] = cp_mix_rec(rec[j][0], gm);
+        const uint32_t b = CP ? cp_b1(rec[j][0], gm) : hash_b1(rec_hash<NL>(rec[j]), gm);
         const uint32_t rank = atomicAdd(&L.sp.hist[buf][b], 1u);
         br[j] = b | (rank << 10);
         n_ins++;
@@ -560,8 +607,10 @@ __global__ __launch_bounds__(WGB) void kc_l1_records_kernel(const uint64_t *recs
     }
     lds_barrier();
     split_round<NL, RPOS>(
-        L.sp, sorted, nullptr, buf, P1, rec, br, D, cst, [&](uint64_t h) { return hash_b1(h, gm); },
-        [&](uint32_t, const uint64_t (&r)[NL]) { l1_overflow<NL>(bb, cb, r); });
+        L.sp, sorted, nullptr, buf, P1, rec, br, D, cst,
+        [&](const uint64_t (&r)[NL]) { return CP ? cp_b1(r[0], gm) : hash_b1(rec_hash<NL>(r), gm); },
+        [&](uint32_t, const uint64_t (&r)[NL]) { l1_overflow<NL, CP>(gm, bb, cb, r); },
+        [&](size_t i, const uint64_t (&r)[NL]) { store_words<NL>(D.arena, i, r); });
     buf ^= 1;
   }
   if ((uint32_t)tid < P1) bb.cnt1[(size_t)g * P1 + tid] = cst.cur;
@@ -585,6 +634,12 @@ template <int NL>
 __device__ __forceinline__ const uint64_t *l2_record(const Geom &gm, const BucketBufs &bb, size_t r, uint32_t i) {
   const uint32_t chunk = bb.chain2[r * gm.L2MAX + (i >> gm.log2CH2)];
   return bb.rec2 + (((size_t)chunk << gm.log2CH2) + (i & ((1u << gm.log2CH2) - 1u))) * NL;
+}
+
+// compact records: 32 bits each
+__device__ __forceinline__ const uint32_t *l2_record32(const Geom &gm, const BucketBufs &bb, size_t r, uint32_t i) {
+  const uint32_t chunk = bb.chain2[r * gm.L2MAX + (i >> gm.log2CH2)];
+  return reinterpret_cast<const uint32_t *>(bb.rec2) + (((size_t)chunk << gm.log2CH2) + (i & ((1u << gm.log2CH2) - 1u)));
 }
 
 // ---- between the levels: every bucket gets a private, exactly sized part of the level-2 arena ---------
@@ -612,7 +667,8 @@ struct L2LDS {
   uint32_t pre[GMAX + 1];  // prefix of the bucket's G segment lengths
 };
 
-template <int NL>
+// CP: the records are mixed ones; what leaves for the regions is their 32-bit remainder (cp_pack32)
+template <int NL, bool CP>
 __global__ __launch_bounds__(WGB) void kc_l2_split_kernel(Geom gm, BucketBufs bb, uint64_t *cb) {
   extern __shared__ __align__(16) uint8_t smem[];
   L2LDS &L = *reinterpret_cast<L2LDS *>(smem);
@@ -674,7 +730,7 @@ __global__ __launch_bounds__(WGB) void kc_l2_split_kernel(Geom gm, BucketBufs bb
         const uint32_t e = v0 + (uint32_t)j * WGB + tid;
         br[j] = ~0u;
         if (e < n) {
-          const uint32_t b = hash_b2(rec_hash<NL>(rec[j]), gm);
+          const uint32_t b = CP ? cp_b2(rec[j][0], gm) : hash_b2(rec_hash<NL>(rec[j]), gm);
           const uint32_t rank = atomicAdd(&L.sp.hist[buf][b], 1u);
           br[j] = b | (rank << 10);
         }
@@ -682,16 +738,21 @@ __global__ __launch_bounds__(WGB) void kc_l2_split_kernel(Geom gm, BucketBufs bb
       KC_SPLIT_STAMP(0)  // wait for the records, issue the next loads, histogram
       lds_barrier();
       split_round<NL, RPOS>(
-          L.sp, sorted, nullptr, buf, P2, rec, br, D, cst, [&](uint64_t h) { return hash_b2(h, gm); },
+          L.sp, sorted, nullptr, buf, P2, rec, br, D, cst,
+          [&](const uint64_t (&r)[NL]) { return CP ? cp_b2(r[0], gm) : hash_b2(rec_hash<NL>(r), gm); },
           [&](uint32_t b, const uint64_t (&r)[NL]) {
             bb.flag[(size_t)b1 * P2 + b] = 1;
             const uint64_t o = atomicAdd((unsigned long long *)&cb[CB_OVF2], 1ULL);
             if (o < bb.ovf2_cap) {
 #pragma unroll
-              for (int w = 0; w < NL; w++) bb.ovf2[o * NL + w] = r[w];
+              for (int w = 0; w < NL; w++) bb.ovf2[o * NL + w] = (CP && w == 0) ? cp_unmix_rec(r[w], gm) : r[w];
             } else {
               cb[CB_FATAL] = 1;
             }
+          },
+          [&](size_t i, const uint64_t (&r)[NL]) {
+            if (CP) reinterpret_cast<uint32_t *>(D.arena)[i] = cp_pack32(r[0], gm);
+            else store_words<NL>(D.arena, i, r);
           });
       buf ^= 1;
     }
@@ -702,14 +763,20 @@ __global__ __launch_bounds__(WGB) void kc_l2_split_kernel(Geom gm, BucketBufs bb
 
 // level-1 overflow records have no region yet (rare path): they join the flagged regions' overflow list and
 // their region is flagged, so the region is handled whole by the global table
-template <int NL>
+template <int NL, bool CP>
 __global__ void kc_ovf1_to_regions_kernel(Geom gm, BucketBufs bb, uint64_t n, uint64_t *cb) {
   const uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
   if (i >= n) return;
   uint64_t r[NL];
   for (int w = 0; w < NL; w++) r[w] = bb.ovf1[i * NL + w];
-  const uint64_t h = rec_hash<NL>(r);
-  const size_t reg = (size_t)hash_b1(h, gm) * gm.P2 + hash_b2(h, gm);
+  size_t reg;
+  if (CP) {
+    const uint64_t m = cp_mix_rec(r[0], gm);
+    reg = (size_t)cp_b1(m, gm) * gm.P2 + cp_b2(m, gm);
+  } else {
+    const uint64_t h = rec_hash<NL>(r);
+    reg = (size_t)hash_b1(h, gm) * gm.P2 + hash_b2(h, gm);
+  }
   bb.flag[reg] = 1;
   const uint64_t o = atomicAdd((unsigned long long *)&cb[CB_OVF2], 1ULL);
   if (o < bb.ovf2_cap) {
@@ -871,10 +938,30 @@ __device__ __forceinline__ uint32_t lds_probe1(unsigned long long *claim, uint32
   return slot;
 }
 
+// The same probe on 32-bit keys (compact records): a 32-bit LDS compare-and-swap runs at about three times the rate
+// of a 64-bit one.  EMPTY is all ones, which no key is (a key has at most 26 bits).
+__device__ __forceinline__ uint32_t lds_probe32(uint32_t *claim, uint32_t Sm1, uint32_t key, uint32_t slot, uint32_t valid, uint32_t &failed) {
+  uint32_t act = valid, trips = 0;
+  do {
+    uint32_t old = key;  // a lane that is done looks like a hit below
+    if (act) old = atomicCAS(&claim[slot], 0xFFFFFFFFu, key);
+    const uint32_t miss = min(old ^ key, ~old) ? act : 0u;  // neither this key nor (until now) empty
+    act = miss;
+    slot = (slot + miss) & Sm1;
+    if (++trips > Sm1 + 1) {  // every slot holds some other k-mer (wave-uniform exit)
+      failed |= act;
+      break;
+    }
+  } while (__any(act));
+  return slot;
+}
+
 // DUMP = false: S7 vote + S8 purge, survivors to the result arrays.  DUMP = true: every entry with its raw
 // (clipped) counters, for tests of S5/S6; no statistics are touched.
 // __launch_bounds__(WGB, 8): two 1024-thread workgroups per CU need at most 64 registers per lane.
-template <int NL, bool DUMP>
+// CP: compact 32-bit records (cp_pack32); the table keys are their upper 26 bits, the k-mer is rebuilt from the
+// region and the key when an entry is written out.
+template <int NL, bool DUMP, bool CP>
 __global__ __launch_bounds__(WGB, 8) void kc_count_kernel(Geom gm, BucketBufs bb, OutBufs out, int dmin_thres, uint64_t *ctrs,
                                                        uint64_t *cb) {
   extern __shared__ __align__(16) uint8_t smem[];
@@ -898,22 +985,21 @@ __global__ __launch_bounds__(WGB, 8) void kc_count_kernel(Geom gm, BucketBufs bb
 #define KC_STAMP(k)
 #endif
   // the table is cleared once; every region leaves it clean again by resetting exactly the slots it claimed
-  for (uint32_t s = tid; s < S; s += WGB) {
-#pragma unroll
-    for (int w = 0; w < NL; w++) tb.keys[w * SM + s] = KEY_EMPTY;
-    tb.cnt[s] = 0;
-#pragma unroll
-    for (int e = 0; e < 4; e++) tb.ext[e * SM + s] = 0;
-  }
-  if (tid == 0) T.nocc = 0;
-  __syncthreads();
+  uint32_t *const keys32 = reinterpret_cast<uint32_t *>(tb.keys);  // CP: the key array holds 32-bit keys
   auto reset_slot = [&](uint32_t s) {
+    if (CP) {
+      keys32[s] = 0xFFFFFFFFu;
+    } else {
 #pragma unroll
-    for (int w = 0; w < NL; w++) tb.keys[w * SM + s] = KEY_EMPTY;
+      for (int w = 0; w < NL; w++) tb.keys[w * SM + s] = KEY_EMPTY;
+    }
     tb.cnt[s] = 0;
 #pragma unroll
     for (int e = 0; e < 4; e++) tb.ext[e * SM + s] = 0;
   };
+  for (uint32_t s = tid; s < S; s += WGB) reset_slot(s);
+  if (tid == 0) T.nocc = 0;
+  __syncthreads();
   for (size_t r = blockIdx.x; r < R; r += gridDim.x) {
     const uint32_t n = bb.cnt2[r];
     if (n == 0 || bb.flag[r]) continue;  // uniform across the workgroup
@@ -939,20 +1025,39 @@ __global__ __launch_bounds__(WGB, 8) void kc_count_kernel(Geom gm, BucketBufs bb
     const uint32_t CHm = (1u << gm.log2CH2) - 1u;
     for (uint32_t i0 = 0; i0 < n; i0 += WGB * BATCH) {
       uint64_t rec[BATCH][NL];
+      uint32_t rec32[BATCH];
       // no branches around the loads (an out-of-range lane re-reads record 0): the compiler can then issue
       // all of them before the first wait instead of fencing each one off in its own basic block
-      const uint64_t *src[BATCH];
+      size_t at[BATCH];
 #pragma unroll
       for (int j = 0; j < BATCH; j++) {
         uint32_t i = i0 + (uint32_t)j * WGB + tid;
         i = i < n ? i : 0u;
-        src[j] = bb.rec2 + (((size_t)T.chain[i >> gm.log2CH2] << gm.log2CH2) + (i & CHm)) * NL;
+        at[j] = ((size_t)T.chain[i >> gm.log2CH2] << gm.log2CH2) + (i & CHm);
       }
 #pragma unroll
-      for (int j = 0; j < BATCH; j++)
+      for (int j = 0; j < BATCH; j++) {
+        if (CP) {
+          rec32[j] = reinterpret_cast<const uint32_t *>(bb.rec2)[at[j]];
+        } else {
 #pragma unroll
-        for (int w = 0; w < NL; w++) rec[j][w] = src[j][w];
-      if constexpr (NL == 1) {
+          for (int w = 0; w < NL; w++) rec[j][w] = bb.rec2[at[j] * NL + w];
+        }
+      }
+      if constexpr (NL == 1 && CP) {
+        uint32_t failed = 0;
+#pragma unroll
+        for (int j = 0; j < BATCH; j++) {
+          const uint32_t v = (i0 + (uint32_t)j * WGB + tid) < n ? 1u : 0u;
+          const uint32_t r0 = rec32[j], key = r0 >> 6;
+          const uint32_t s = lds_probe32(keys32, S - 1u, key, key & (S - 1u), v, failed);
+          const uint32_t le = r0 & 7u, re = (r0 >> 3) & 7u;
+          atomicAdd(&tb.cnt[s], v);
+          atomicAdd(&tb.ext[((le >> 1) & 1u) * SM + s], (v << ((le & 1u) << 4)) & (((le >> 2) & 1u) - 1u));
+          atomicAdd(&tb.ext[(2u + ((re >> 1) & 1u)) * SM + s], (v << ((re & 1u) << 4)) & (((re >> 2) & 1u) - 1u));
+        }
+        if (failed) T.fail = 1;
+      } else if constexpr (NL == 1) {
         uint32_t failed = 0;
 #pragma unroll
         for (int j = 0; j < BATCH; j++) {
@@ -1039,8 +1144,12 @@ __global__ __launch_bounds__(WGB, 8) void kc_count_kernel(Geom gm, BucketBufs bb
       if (p != ~0u) {
         const uint64_t o = gbase + (p >> 20);
         if (o < out.cap) {  // beyond the arrays: the host sees the cursor past cap and re-runs with more room
+          if (CP) {
+            out.keys[o] = cp_unpack_rec(keys32[s] << 6, r, gm);
+          } else {
 #pragma unroll
-          for (int w = 0; w < NL; w++) out.keys[o * NL + w] = tb.keys[w * SM + s];
+            for (int w = 0; w < NL; w++) out.keys[o * NL + w] = tb.keys[w * SM + s];
+          }
           out.counts[o] = (uint16_t)(p & 0xFFFFu);
           if (DUMP) {
 #pragma unroll
@@ -1064,16 +1173,20 @@ __global__ __launch_bounds__(WGB, 8) void kc_count_kernel(Geom gm, BucketBufs bb
 }
 
 // records of flagged regions go to the global table (kc_kernels.hpp): one workgroup per flagged region at a time
-template <int NL>
+template <int NL, bool CP>
 __global__ __launch_bounds__(TPB) void kc_flagged_to_table_kernel(Geom gm, BucketBufs bb, Table t, uint64_t *ctrs) {
   const size_t R = (size_t)gm.P1 * gm.P2;
   for (size_t r = blockIdx.x; r < R; r += gridDim.x) {
     if (!bb.flag[r]) continue;
     const uint32_t n = bb.cnt2[r];
     for (uint32_t i = threadIdx.x; i < n; i += TPB) {
-      const uint64_t *src = l2_record<NL>(gm, bb, r, i);
       uint64_t rec[NL];
-      for (int w = 0; w < NL; w++) rec[w] = src[w];
+      if (CP) {
+        rec[0] = cp_unpack_rec(*l2_record32(gm, bb, r, i), r, gm);
+      } else {
+        const uint64_t *src = l2_record<NL>(gm, bb, r, i);
+        for (int w = 0; w < NL; w++) rec[w] = src[w];
+      }
       table_insert<NL>(t, rec, ctrs);
     }
   }
@@ -1081,7 +1194,7 @@ __global__ __launch_bounds__(TPB) void kc_flagged_to_table_kernel(Geom gm, Bucke
 
 // every buffered level-1 record goes to the global table (the context ran out of buffer room and
 // switches to the table path for good)
-template <int NL>
+template <int NL, bool CP>
 __global__ __launch_bounds__(TPB) void kc_l1_to_table_kernel(Geom gm, BucketBufs bb, Table t, uint64_t *ctrs) {
   const size_t nseg = (size_t)gm.G * gm.P1;
   for (size_t sgi = blockIdx.x; sgi < nseg; sgi += gridDim.x) {
@@ -1091,6 +1204,7 @@ __global__ __launch_bounds__(TPB) void kc_l1_to_table_kernel(Geom gm, BucketBufs
       const uint64_t *src = l1_record<NL>(gm, bb, g, b, i);
       uint64_t rec[NL];
       for (int w = 0; w < NL; w++) rec[w] = src[w];
+      if (CP) rec[0] = cp_unmix_rec(rec[0], gm);
       table_insert<NL>(t, rec, ctrs);
     }
   }

@@ -126,6 +126,37 @@ KC_HD uint64_t kc_hash(const uint64_t (&key)[NL]) {
   return ((uint64_t)(a2 ^ b2) << 32) | (uint64_t)(a ^ b);
 }
 
+// ---- an invertible mix of a short k-mer (k <= 23): four Feistel rounds on its two k-bit halves -------------------
+// The bucketed path of one-word k-mers splits and probes on the bits of this value instead of a hash of the k-mer:
+// because the map is a bijection, the bits that name a record's bucket and region need not be stored with it, which
+// halves the records of the second level, and the k-mer is recovered from (region, remaining bits) when the results
+// are written.  Round function: the top k bits of the low 32 bits of x * C + D (24-bit multiply: full VALU rate).
+KC_HD uint32_t kc_feistel_f(uint32_t x, int i, int k) {
+  const uint32_t C[4] = {0x9E3779u, 0x85EBCBu, 0xC2B2AFu, 0x27D4EBu}, D[4] = {0x7F4A7Cu, 0x165667u, 0x3C6EF3u, 0x5BD1E9u};
+#if defined(__HIP_DEVICE_COMPILE__)
+  return (__umul24(x, C[i]) + D[i]) >> (32 - k);
+#else
+  return (x * C[i] + D[i]) >> (32 - k);
+#endif
+}
+KC_HD uint64_t kc_feistel_fwd(uint64_t v, int k) {  // v < 4^k
+  uint32_t L = (uint32_t)(v >> k), R = (uint32_t)v & ((1u << k) - 1u);
+  L ^= kc_feistel_f(R, 0, k);
+  R ^= kc_feistel_f(L, 1, k);
+  L ^= kc_feistel_f(R, 2, k);
+  R ^= kc_feistel_f(L, 3, k);
+  return ((uint64_t)L << k) | R;
+}
+KC_HD uint64_t kc_feistel_inv(uint64_t m, int k) {
+  uint32_t L = (uint32_t)(m >> k), R = (uint32_t)m & ((1u << k) - 1u);
+  R ^= kc_feistel_f(L, 3, k);
+  L ^= kc_feistel_f(R, 2, k);
+  R ^= kc_feistel_f(L, 1, k);
+  L ^= kc_feistel_f(R, 0, k);
+  return ((uint64_t)L << k) | R;
+}
+constexpr int KC_COMPACT_MAX_K = 23;
+
 KC_HD uint32_t kc_owner_of_hash(uint64_t h, uint32_t rank_n) {
   return (uint32_t)(((h >> 32) * (uint64_t)rank_n) >> 32);
 }

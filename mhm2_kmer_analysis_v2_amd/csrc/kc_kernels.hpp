@@ -510,7 +510,9 @@ __device__ __forceinline__ void run_begin(KmerRun<NL> &s, const TL &L, int lp0, 
 }
 
 // the k-mer at position lp0 + j (the run has been advanced j times); same outputs as tile_kmer
-template <int NL>
+// HASH = false: the caller has no use for the k-mer hash (h is left alone; *owner is only set for the reference's
+// partition function)
+template <int NL, bool HASH = true>
 __device__ __forceinline__ bool run_kmer(const KmerRun<NL> &s, int j, int lp0, int k, uint64_t (&rec)[NL], uint64_t &h, uint32_t rank_n = 1,
                                          uint32_t reference_owner = 0, uint32_t *owner = nullptr) {
   const uint32_t c = (uint32_t)(s.nextb >> 62);
@@ -526,8 +528,10 @@ __device__ __forceinline__ bool run_kmer(const KmerRun<NL> &s, int j, int lp0, i
   const uint32_t nr = (le == KC_EXT_NONE) ? KC_EXT_NONE : 3u - le;
   le = swap ? nl : le;
   re = swap ? nr : re;
-  h = kc_hash<NL>(f);
-  if (owner && rank_n > 1 && !reference_owner) *owner = kc_owner_of_hash(h, rank_n);
+  if (HASH) {
+    h = kc_hash<NL>(f);
+    if (owner && rank_n > 1 && !reference_owner) *owner = kc_owner_of_hash(h, rank_n);
+  }
 #pragma unroll
   for (int w = 0; w < NL; w++) rec[w] = f[w];
   rec[NL - 1] |= (uint64_t)(le | (re << 3));

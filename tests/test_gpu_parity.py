@@ -32,16 +32,20 @@ def arrays(reads, quals):
 
 # the two insert paths of the library: bucketed (LDS-counted regions, the default) and the global table;
 # "small" forces a real two-level partition with several writers on inputs the oracle finishes in seconds
+# "compact": one-word k-mers with k <= 23 travel as an invertible mix of the k-mer and the regions hold 32-bit
+# records (power-of-two fan-outs that imply enough bits); "wide" switches that off
 PATHS = {
     "bucketed": None,
     "bucketed-small": dict(writers=3, p1=4, p2=8, slots=512),
     "bucketed-odd": dict(writers=5, p1=7, p2=13, slots=256),
+    "compact": dict(writers=3, p1=256, p2=256, slots=512),
+    "wide": dict(mode=2, writers=3, p1=256, p2=256, slots=512),
     "table": dict(mode=1),
 }
 
 
 @pytest.mark.parametrize("path", list(PATHS))
-@pytest.mark.parametrize("k", [21, 29, 33, 51, 55, 64, 77, 99])
+@pytest.mark.parametrize("k", [13, 17, 21, 23, 29, 33, 51, 55, 64, 77, 99])
 def test_random_reads_match_oracle(k, path):
     rng = np.random.default_rng(100 + k)
     reads, quals = random_reads(rng, 1500, min_len=max(3, k - 5), max_len=k + 130, genome_len=3000)
@@ -301,7 +305,7 @@ def _reads_for_overflow(seed=21, n=1200):
     return random_reads(rng, n, min_len=40, max_len=160, genome_len=4000)
 
 
-@pytest.mark.parametrize("k", [21, 51])
+@pytest.mark.parametrize("k", [13, 21, 51])  # k=13: compact records with these small power-of-two fan-outs
 @pytest.mark.parametrize("tuning", [
     dict(writers=2, p1=2, p2=4, slots=4096, chunk1=16, chain1_max=8, ovf_capacity=1 << 20),   # level-1 chains overflow
     dict(writers=2, p1=2, p2=4, slots=4096, chunk1=16, arena1=20, ovf_capacity=1 << 20),      # a writer's arena runs out

@@ -1050,11 +1050,16 @@ __global__ __launch_bounds__(WGB, 8) void kc_count_kernel(Geom gm, BucketBufs bb
         for (int j = 0; j < BATCH; j++) {
           const uint32_t v = (i0 + (uint32_t)j * WGB + tid) < n ? 1u : 0u;
           const uint32_t r0 = rec32[j], key = r0 >> 6;
+          if (!__any(v)) continue;  // past the end of the region for the whole wave
           const uint32_t s = lds_probe32(keys32, S - 1u, key, key & (S - 1u), v, failed);
           const uint32_t le = r0 & 7u, re = (r0 >> 3) & 7u;
-          atomicAdd(&tb.cnt[s], v);
-          atomicAdd(&tb.ext[((le >> 1) & 1u) * SM + s], (v << ((le & 1u) << 4)) & (((le >> 2) & 1u) - 1u));
-          atomicAdd(&tb.ext[(2u + ((re >> 1) & 1u)) * SM + s], (v << ((re & 1u) << 4)) & (((re >> 2) & 1u) - 1u));
+          // only lanes that hold a record touch the counters: the idle lanes of a wave all re-read record 0, and 64
+          // atomic adds of zero to one LDS word are serialised
+          if (v) {
+            atomicAdd(&tb.cnt[s], 1u);
+            atomicAdd(&tb.ext[((le >> 1) & 1u) * SM + s], (1u << ((le & 1u) << 4)) & (((le >> 2) & 1u) - 1u));
+            atomicAdd(&tb.ext[(2u + ((re >> 1) & 1u)) * SM + s], (1u << ((re & 1u) << 4)) & (((re >> 2) & 1u) - 1u));
+          }
         }
         if (failed) T.fail = 1;
       } else if constexpr (NL == 1) {
@@ -1064,12 +1069,16 @@ __global__ __launch_bounds__(WGB, 8) void kc_count_kernel(Geom gm, BucketBufs bb
           const uint32_t v = (i0 + (uint32_t)j * WGB + tid) < n ? 1u : 0u;
           const uint64_t r0 = rec[j][0], key = r0 & ~KC_EXT_MASK;
           uint64_t kk[1] = {key};
+          if (!__any(v)) continue;  // past the end of the region for the whole wave
           const uint32_t s = lds_probe1((unsigned long long *)tb.keys, S - 1u, key, hash_slot(kc_hash<1>(kk), S), v, failed);
-          // S5/S6: the k-mer itself, and each extension that is an ACGT base (codes 0-3; 4 = none adds 0)
+          // S5/S6: the k-mer itself, and each extension that is an ACGT base (codes 0-3; 4 = none adds 0).  Only
+          // lanes that hold a record touch the counters (see the compact path above)
           const uint32_t le = (uint32_t)r0 & 7u, re = ((uint32_t)r0 >> 3) & 7u;
-          atomicAdd(&tb.cnt[s], v);
-          atomicAdd(&tb.ext[((le >> 1) & 1u) * SM + s], (v << ((le & 1u) << 4)) & (((le >> 2) & 1u) - 1u));
-          atomicAdd(&tb.ext[(2u + ((re >> 1) & 1u)) * SM + s], (v << ((re & 1u) << 4)) & (((re >> 2) & 1u) - 1u));
+          if (v) {
+            atomicAdd(&tb.cnt[s], 1u);
+            atomicAdd(&tb.ext[((le >> 1) & 1u) * SM + s], (1u << ((le & 1u) << 4)) & (((le >> 2) & 1u) - 1u));
+            atomicAdd(&tb.ext[(2u + ((re >> 1) & 1u)) * SM + s], (1u << ((re & 1u) << 4)) & (((re >> 2) & 1u) - 1u));
+          }
         }
         if (failed) T.fail = 1;
       } else {

@@ -60,6 +60,7 @@ struct kc_ctx {
   uint64_t *d_ctrs;
   uint64_t *h_ctrs;  // pinned mirror
   uint64_t *d_tile_first;
+  uint64_t *d_out_plan;  // hole-closing plan + per-workgroup tails of the block-wise result output
   size_t tile_first_cap;
   // staging for host-resident input
   uint8_t *d_stage_bases, *d_stage_quals;
@@ -360,6 +361,7 @@ extern "C" void kc_destroy(kc_ctx *c) {
   if (c->d_ctrs) (void)hipFree(c->d_ctrs);
   if (c->h_ctrs) (void)hipHostFree(c->h_ctrs);
   if (c->d_tile_first) (void)hipFree(c->d_tile_first);
+  if (c->d_out_plan) (void)hipFree(c->d_out_plan);
   if (c->d_stage_bases) (void)hipFree(c->d_stage_bases);
   if (c->d_stage_quals) (void)hipFree(c->d_stage_quals);
   if (c->d_stage_offsets) (void)hipFree(c->d_stage_offsets);
@@ -1262,11 +1264,20 @@ static int bk_finalize(kc_ctx *c) {
   // survivors have count >= 2, so at most half the buffered occurrences; usually far fewer
   uint64_t cap = std::max<uint64_t>(1u << 16, std::min<uint64_t>(c->h_ctrs[CTR_INSERTED] / 2 + 1,
                                                                    c->cfg.max_elems ? c->cfg.max_elems / 2 : c->h_ctrs[CTR_INSERTED] / 8 + 1));
+  // Output positions are handed out in blocks per workgroup (OutBufs::block); the unused tails are closed afterwards.
+  // The arrays need room for one block per workgroup beyond the entries themselves.
+  const uint32_t max_wg = 2u * (uint32_t)c->num_cus;
+  const uint32_t block = max_wg < PLAN_RUNS ? 8192u : 0u;
+  if (block && !c->d_out_plan) {
+    HIPCHK(hipMalloc((void **)&c->d_out_plan, (PLAN_WORDS + 2 * (size_t)max_wg) * 8));
+  }
+  const uint64_t slack = (uint64_t)block * max_wg;
+  cap += slack;
   for (int attempt = 0; attempt < 3; attempt++) {
     rc = alloc_results(c, cap);
     if (rc) return rc;
     HIPCHK(hipMemsetAsync(c->d_ctrs + CTR_OUT, 0, 3 * 8, c->stream));  // OUT, PURGED, SUM_COUNTS
-    HIPCHK(hipMemsetAsync(c->d_cb + CB_ENTRIES, 0, 8, c->stream));
+    HIPCHK(hipMemsetAsync(c->d_cb + CB_ENTRIES, 0, 2 * 8, c->stream));  // ENTRIES, OUT_RESERVED
     OutBufs ob;
     ob.keys = c->d_out_keys;
     ob.counts = c->d_out_counts;
@@ -1275,10 +1286,34 @@ static int bk_finalize(kc_ctx *c) {
     ob.exts = nullptr;
     ob.cap = c->out_cap;
     ob.cursor = c->d_ctrs + CTR_OUT;
+    ob.block = block;
+    ob.tails = block ? c->d_out_plan + PLAN_WORDS : nullptr;
+    if (block) HIPCHK(hipMemsetAsync(ob.tails, 0, 2 * (size_t)max_wg * 8, c->stream));
     rc = bk_count(c, ob, false);
     if (rc) return rc;
+    if (block) {
+      hipLaunchKernelGGL(kc_out_plan_kernel, dim3(1), dim3(WGB), 0, c->stream, ob.tails, max_wg, ob.cursor, c->d_cb + CB_OUT_RESERVED,
+                         c->d_out_plan);
+      const unsigned mgrid = (unsigned)std::min<uint64_t>((slack + 255) / 256, 4096);
+      switch (c->nl) {
+        case 1: hipLaunchKernelGGL(kc_out_move_kernel<1>, dim3(mgrid), dim3(256), 0, c->stream, c->d_out_plan, ob); break;
+        case 2: hipLaunchKernelGGL(kc_out_move_kernel<2>, dim3(mgrid), dim3(256), 0, c->stream, c->d_out_plan, ob); break;
+        case 3: hipLaunchKernelGGL(kc_out_move_kernel<3>, dim3(mgrid), dim3(256), 0, c->stream, c->d_out_plan, ob); break;
+        default: hipLaunchKernelGGL(kc_out_move_kernel<4>, dim3(mgrid), dim3(256), 0, c->stream, c->d_out_plan, ob); break;
+      }
+      c->num_gpu_calls += 2;
+      HIPCHK(hipGetLastError());
+    }
     rc = sync_ctrs(c);
     if (rc) return rc;
+    if (block) {
+      rc = sync_cb(c);
+      if (rc) return rc;
+      // every block ever taken must lie inside the arrays, or entries were dropped: run again with enough room
+      if (c->h_cb[CB_OUT_RESERVED] <= c->out_cap) break;
+      cap = c->h_ctrs[CTR_OUT] + slack;
+      continue;
+    }
 #ifdef KC_STAMPS
     (void)sync_cb(c);
     fprintf(stderr, "count kernel cycles (thread 0, summed over workgroups): zero %llu insert %llu satscan %llu vote %llu write %llu\n",

@@ -79,7 +79,7 @@ struct BucketBufs {
 };
 
 enum {  // counters of this path, one u64 each
-  CB_OVF1 = 0, CB_OVF2, CB_FATAL, CB_FLAGGED_RECS, CB_DUMP, CB_ENTRIES, CB_COUNT = 16
+  CB_OVF1 = 0, CB_OVF2, CB_FATAL, CB_FLAGGED_RECS, CB_DUMP, CB_ENTRIES, CB_OUT_RESERVED, CB_COUNT = 16
 };
 
 // Four independent fields of the 64-bit k-mer hash: bits 0-15 pick the level-1 bucket, 16-31 the level-2 bucket
@@ -799,6 +799,7 @@ struct CountLDS {  // header at the start of the dynamic LDS; the arrays follow,
   static constexpr uint32_t SMAX = NL <= 2 ? 4096 : 2048;
   uint32_t chain[CHAIN_LDS];  // the region's chunk ids
   uint32_t nout, nocc, fail, gbase_lo, gbase_hi;
+  uint32_t gbase2_lo, gbase2_hi, split;  // ranks >= split continue at gbase2 (a region may straddle two blocks)
   unsigned long long sum;
   static constexpr size_t header_bytes() { return (sizeof(CountLDS<NL>) + 15) & ~size_t(15); }
   static constexpr size_t bytes(uint32_t S) { return header_bytes() + (size_t)S * (8 * NL + 20 + 2); }
@@ -842,6 +843,12 @@ struct OutBufs {
   uint16_t *exts;    // DUMP only: 8 per entry
   uint64_t cap;
   uint64_t *cursor;  // global append position (results: &ctrs[CTR_OUT])
+  // block > 0: a workgroup takes its output positions from private blocks of `block` entries and bumps the cursor
+  // only when a block is used up (a bump per region makes every workgroup of the chip queue on one address: measured
+  // 16 of the count kernel's 42 ms).  Each workgroup leaves the unused tail of its last block in tails[2*wg], and
+  // kc_out_plan_kernel / kc_out_move_kernel then close those holes with entries from the end of the arrays.
+  uint32_t block;
+  uint64_t *tails;   // [2 * workgroups]: start and length of the hole
 };
 
 // append the slots that lanes have just claimed to the region's list: one LDS atomic per wave
@@ -1000,6 +1007,8 @@ __global__ __launch_bounds__(WGB, 8) void kc_count_kernel(Geom gm, BucketBufs bb
   for (uint32_t s = tid; s < S; s += WGB) reset_slot(s);
   if (tid == 0) T.nocc = 0;
   __syncthreads();
+  // thread 0: this workgroup's output block and its share of the statistics (flushed once, at the end)
+  uint64_t blk_base = 0, blk_left = 0, acc_entries = 0, acc_purged = 0, acc_sum = 0;
   for (size_t r = blockIdx.x; r < R; r += gridDim.x) {
     const uint32_t n = bb.cnt2[r];
     if (n == 0 || bb.flag[r]) continue;  // uniform across the workgroup
@@ -1134,24 +1143,45 @@ __global__ __launch_bounds__(WGB, 8) void kc_count_kernel(Geom gm, BucketBufs bb
       continue;
     }
     if (tid == 0) {
-      const uint64_t gb = atomicAdd((unsigned long long *)out.cursor, (unsigned long long)T.nout);
+      const uint32_t need = T.nout;
+      uint64_t gb, gb2 = 0;
+      uint32_t split = need;
+      if (out.block == 0) {
+        gb = atomicAdd((unsigned long long *)out.cursor, (unsigned long long)need);
+      } else {
+        // from this workgroup's current block first, then from fresh ones (thread 0 keeps the block in registers)
+        gb = blk_base;
+        split = need < blk_left ? need : (uint32_t)blk_left;
+        blk_base += split;
+        blk_left -= split;
+        const uint32_t rest = need - split;
+        if (rest) {
+          const uint64_t take = ((uint64_t)rest + out.block - 1) / out.block * out.block;
+          gb2 = atomicAdd((unsigned long long *)out.cursor, (unsigned long long)take);
+          blk_base = gb2 + rest;
+          blk_left = take - rest;
+        }
+      }
       T.gbase_lo = (uint32_t)gb;
       T.gbase_hi = (uint32_t)(gb >> 32);
-      if (!DUMP) {
-        atomicAdd((unsigned long long *)&cb[CB_ENTRIES], (unsigned long long)nocc);
-        atomicAdd((unsigned long long *)&ctrs[CTR_PURGED], (unsigned long long)(nocc - T.nout));
-        atomicAdd((unsigned long long *)&ctrs[CTR_SUM_COUNTS], T.sum);
-      }
+      T.gbase2_lo = (uint32_t)gb2;
+      T.gbase2_hi = (uint32_t)(gb2 >> 32);
+      T.split = split;
+      acc_entries += nocc;
+      acc_purged += nocc - need;
+      acc_sum += T.sum;
       T.nocc = 0;  // every thread has its copy; the next region starts an empty list
     }
     __syncthreads();
     KC_STAMP(3)  // vote + reserve
-    const uint64_t gbase = ((uint64_t)T.gbase_hi << 32) | T.gbase_lo;
+    const uint64_t gbase = ((uint64_t)T.gbase_hi << 32) | T.gbase_lo, gbase2 = ((uint64_t)T.gbase2_hi << 32) | T.gbase2_lo;
+    const uint32_t split = T.split;
     for (uint32_t e = tid; e < nocc; e += WGB) {
       const uint32_t s = tb.occ[e];
       const uint32_t p = tb.cnt[s];
       if (p != ~0u) {
-        const uint64_t o = gbase + (p >> 20);
+        const uint32_t rank = p >> 20;
+        const uint64_t o = rank < split ? gbase + rank : gbase2 + (rank - split);
         if (o < out.cap) {  // beyond the arrays: the host sees the cursor past cap and re-runs with more room
           if (CP) {
             out.keys[o] = cp_unpack_rec(keys32[s] << 6, r, gm);
@@ -1174,11 +1204,122 @@ __global__ __launch_bounds__(WGB, 8) void kc_count_kernel(Geom gm, BucketBufs bb
     __syncthreads();
     KC_STAMP(4)  // write out + clean
   }
+  if (tid == 0) {
+    if (!DUMP) {
+      atomicAdd((unsigned long long *)&cb[CB_ENTRIES], (unsigned long long)acc_entries);
+      atomicAdd((unsigned long long *)&ctrs[CTR_PURGED], (unsigned long long)acc_purged);
+      atomicAdd((unsigned long long *)&ctrs[CTR_SUM_COUNTS], (unsigned long long)acc_sum);
+    }
+    if (out.block) {
+      out.tails[2 * blockIdx.x] = blk_base;
+      out.tails[2 * blockIdx.x + 1] = blk_left;
+    }
+  }
 #ifdef KC_STAMPS
   if (stamp)
     for (int k = 0; k < 5; k++) atomicAdd((unsigned long long *)&cb[8 + k], tacc[k]);
 #endif
 #undef KC_STAMP
+}
+
+// ---- closing the holes that block-wise output leaves (OutBufs::block) ------------------------------------------------
+// plan[0] = entries to move, plan[1] = holes below the final size, plan[2] = source runs; then the hole runs
+// (start, entries before it) and the source runs, PLAN_RUNS pairs each.
+constexpr uint32_t PLAN_RUNS = 1024;  // at most one hole per workgroup (<= 2 per CU) and one source run between two holes
+constexpr size_t PLAN_WORDS = 4 + 4 * (size_t)(PLAN_RUNS + 1);
+
+// One workgroup.  T = the cursor (every block ever taken), holes = the unused tails; the final size is n = T - sum of
+// the holes.  Holes below n are filled, in order, with the entries that sit at or above n.  Leaves n in *cursor and T
+// in *reserved.
+__global__ __launch_bounds__(WGB) void kc_out_plan_kernel(const uint64_t *tails, uint32_t nwg, uint64_t *cursor, uint64_t *reserved,
+                                                        uint64_t *plan) {
+  __shared__ uint64_t hs[PLAN_RUNS], hl[PLAN_RUNS];  // holes sorted by position
+  __shared__ uint32_t nh;
+  const uint32_t tid = threadIdx.x;
+  if (tid == 0) nh = 0;
+  __syncthreads();
+  // rank the non-empty holes by position (positions are distinct: blocks do not overlap)
+  uint64_t pos = 0, len = 0;
+  if (tid < nwg) {
+    pos = tails[2 * tid];
+    len = tails[2 * tid + 1];
+  }
+  if (len) {
+    uint32_t rank = 0;
+    for (uint32_t j = 0; j < nwg; j++)
+      if (tails[2 * j + 1] && tails[2 * j] < pos) rank++;
+    hs[rank] = pos;
+    hl[rank] = len;
+    atomicAdd(&nh, 1u);
+  }
+  __syncthreads();
+  if (tid == 0) {
+    const uint64_t T = *cursor;
+    uint64_t holes = 0;
+    for (uint32_t i = 0; i < nh; i++) holes += hl[i];
+    const uint64_t n = T - holes;
+    uint64_t *hrun = plan + 4, *srun = plan + 4 + 2 * (PLAN_RUNS + 1);
+    uint64_t nhole = 0, nsrc = 0, hcount = 0, scount = 0;
+    uint64_t at = n;  // walks [n, T): what is not a hole there is a source
+    for (uint32_t i = 0; i < nh; i++) {
+      const uint64_t b = hs[i], e = hs[i] + hl[i];
+      if (b < n) {  // (part of) a hole to fill
+        const uint64_t ee = e < n ? e : n;
+        hrun[2 * nhole] = b;
+        hrun[2 * nhole + 1] = hcount;
+        hcount += ee - b;
+        nhole++;
+      }
+      if (e > n) {  // (part of) a hole in the tail: entries between `at` and it are sources
+        const uint64_t bb = b > n ? b : n;
+        if (bb > at) {
+          srun[2 * nsrc] = at;
+          srun[2 * nsrc + 1] = scount;
+          scount += bb - at;
+          nsrc++;
+        }
+        at = e;
+      }
+    }
+    if (T > at) {
+      srun[2 * nsrc] = at;
+      srun[2 * nsrc + 1] = scount;
+      scount += T - at;
+      nsrc++;
+    }
+    hrun[2 * nhole + 1] = hcount;  // sentinels for the searches
+    srun[2 * nsrc + 1] = scount;
+    plan[0] = hcount < scount ? hcount : scount;  // equal by construction
+    plan[1] = nhole;
+    plan[2] = nsrc;
+    *reserved = T;
+    *cursor = n;
+  }
+}
+
+// entry m of the move: from the m-th source position to the m-th hole position
+template <int NL>
+__global__ void kc_out_move_kernel(const uint64_t *plan, OutBufs out) {
+  const uint64_t nmove = plan[0];
+  const uint32_t nhole = (uint32_t)plan[1], nsrc = (uint32_t)plan[2];
+  const uint64_t *hrun = plan + 4, *srun = plan + 4 + 2 * (PLAN_RUNS + 1);
+  auto locate = [](const uint64_t *run, uint32_t nrun, uint64_t m) -> uint64_t {  // last run whose prefix is <= m
+    uint32_t lo = 0, hi = nrun;
+    while (hi - lo > 1) {
+      const uint32_t mid = (lo + hi) >> 1;
+      if (run[2 * mid + 1] <= m) lo = mid; else hi = mid;
+    }
+    return run[2 * lo] + (m - run[2 * lo + 1]);
+  };
+  for (uint64_t m = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x; m < nmove; m += (uint64_t)gridDim.x * blockDim.x) {
+    const uint64_t d = locate(hrun, nhole, m), sidx = locate(srun, nsrc, m);
+    if (d >= out.cap || sidx >= out.cap) continue;  // the arrays were too small: the host runs the pass again
+#pragma unroll
+    for (int w = 0; w < NL; w++) out.keys[d * NL + w] = out.keys[sidx * NL + w];
+    out.counts[d] = out.counts[sidx];
+    out.left[d] = out.left[sidx];
+    out.right[d] = out.right[sidx];
+  }
 }
 
 // records of flagged regions go to the global table (kc_kernels.hpp): one workgroup per flagged region at a time

@@ -162,11 +162,15 @@ __device__ __forceinline__ uint32_t block_excl_scan(uint32_t v, ScanLDS &S) {
 // ---- multisplit of one round of records held in registers ---------------------------------------
 // LDS working set shared by both split kernels
 struct SplitLDS {
-  uint32_t hist[2][PMAX];  // per-bucket counts of this round (double-buffered); becomes "fit" after the scan
-  uint32_t offs[PMAX];     // exclusive prefix: where the bucket's run starts in the sorted staging
-  uint32_t dbase[PMAX];    // position in the destination chain where the run starts
-  uint32_t c0[PMAX];       // chunk that holds position dbase when the run starts inside an old chunk
-  uint32_t nb[PMAX];       // chunk index ci >= first new one lives in chunk nb + ci (new chunks of a round are consecutive)
+  uint32_t hist[2][PMAX];  // per-bucket counts of this round (double-buffered)
+  // what the copy-out needs to know about a bucket's run, in one 64-bit read: bits 0-15 where the run starts in the
+  // sorted staging (exclusive prefix), 16-31 how many of its records found room, 32-47 how many of those still go
+  // into the chain's old last chunk
+  uint64_t meta[PMAX];
+  // record index (relative to the owner's part of the arena) of the run's element 0 as seen from the old last chunk
+  // [0] and from the round's new chunks [1]: the new chunks of a round are consecutive, so inside either the index
+  // is linear in the element's rank
+  uint32_t ab[2][PMAX];
   uint32_t arena_used;     // chunks taken from the owner's arena
   ScanLDS scan;
 };
@@ -212,13 +216,11 @@ __device__ __forceinline__ void split_round(SplitLDS &L, uint64_t *sorted, uint1
   // sbucket: optional LDS array parallel to `sorted` that remembers each staged record's bucket, so that the copy-out
   // need not hash the record again (null where the LDS has no room for it)
   const int tid = threadIdx.x;
-  uint32_t *H = L.hist[buf];
   KC_SPLIT_STAMP(1)  // barrier after the histogram
-  const uint32_t v = ((uint32_t)tid < P) ? H[tid] : 0u;
+  const uint32_t v = ((uint32_t)tid < P) ? L.hist[buf][tid] : 0u;
   const uint32_t excl = block_excl_scan(v, L.scan);
   const uint32_t CHm = (1u << D.log2CH) - 1u;
   if ((uint32_t)tid < P) {
-    L.offs[tid] = excl;
     const uint32_t base = st.cur;
     uint32_t fit = v;
     const uint64_t room = ((uint64_t)D.LMAX << D.log2CH) - base;  // the chain holds at most LMAX chunks
@@ -235,11 +237,13 @@ __device__ __forceinline__ void split_round(SplitLDS &L, uint64_t *sorted, uint1
       uint32_t *ch = D.chain + (size_t)tid * D.LMAX + have;
       for (uint32_t i = 0; i < k; i++) ch[i] = D.arena_base + a + i;
     }
-    L.c0[tid] = st.last;
-    L.nb[tid] = D.arena_base + a - have;  // unsigned wrap is fine: only used as nb + ci with ci >= have
+    // element j of the run sits at chain position base + j: in the old last chunk (id st.last) while that has room,
+    // then in the new chunks a, a+1, ... whose first one holds chain positions have << log2CH onwards
+    const uint32_t in_old = (base & CHm) ? min(fit, (CHm + 1u) - (base & CHm)) : 0u;
+    L.ab[0][tid] = ((st.last - D.arena_base - (base >> D.log2CH)) << D.log2CH) + base;
+    L.ab[1][tid] = ((a - have) << D.log2CH) + base;
+    L.meta[tid] = (uint64_t)excl | ((uint64_t)fit << 16) | ((uint64_t)in_old << 32);
     if (k) st.last = D.arena_base + a + k - 1;
-    L.dbase[tid] = base;
-    H[tid] = fit;
     st.cur = base + fit;
     L.hist[buf ^ 1][tid] = 0;  // next round's histogram
   }
@@ -250,7 +254,7 @@ __device__ __forceinline__ void split_round(SplitLDS &L, uint64_t *sorted, uint1
   for (int j = 0; j < R; j++) {
     if (br[j] != ~0u) {
       const uint32_t b = br[j] & (PMAX - 1), rank = br[j] >> 10;
-      const uint32_t pos = L.offs[b] + rank;
+      const uint32_t pos = ((uint32_t)L.meta[b] & 0xFFFFu) + rank;
 #pragma unroll
       for (int w = 0; w < NL; w++) sorted[(size_t)pos * NL + w] = rec[j][w];
       if (sbucket) sbucket[pos] = (uint16_t)b;
@@ -258,9 +262,10 @@ __device__ __forceinline__ void split_round(SplitLDS &L, uint64_t *sorted, uint1
   }
   lds_barrier();
   KC_SPLIT_STAMP(3)  // scatter to LDS
-  // copy out, U elements per thread and trip: the LDS reads, the hashes and the bucket look-ups of the U elements are
+  // copy out, U elements per thread and trip: the LDS reads and the bucket look-ups of the U elements are
   // independent chains the hardware can overlap (one element per trip is a single long dependent chain per wave)
   constexpr int U = NL == 1 ? 4 : 2;
+  const size_t arena0 = (size_t)D.arena_base << D.log2CH;
   for (uint32_t i0 = tid; i0 < total; i0 += U * WGB) {
     uint64_t r[U][NL];
     uint32_t b[U];
@@ -285,12 +290,11 @@ __device__ __forceinline__ void split_round(SplitLDS &L, uint64_t *sorted, uint1
     for (int u = 0; u < U; u++) {
       const uint32_t i = i0 + u * WGB;
       if (i >= total) break;
-      const uint32_t j = i - L.offs[b[u]];
-      if (j < H[b[u]]) {
-        const uint32_t db = L.dbase[b[u]], p = db + j, ci = p >> D.log2CH;
-        // the run starts inside the chain's old last chunk (c0) unless it starts chunk-aligned; later chunks are new
-        const uint32_t cid = ((db & CHm) && ci == (db >> D.log2CH)) ? L.c0[b[u]] : L.nb[b[u]] + ci;
-        store(((size_t)cid << D.log2CH) + (p & CHm), r[u]);
+      const uint64_t m = L.meta[b[u]];
+      const uint32_t j = i - ((uint32_t)m & 0xFFFFu);
+      if (j < (((uint32_t)m >> 16) & 0xFFFFu)) {
+        const uint32_t at = L.ab[j >= (uint32_t)(m >> 32) ? 1 : 0][b[u]] + j;
+        store(arena0 + at, r[u]);
       } else {
         overflow(b[u], r[u]);
       }
@@ -461,12 +465,12 @@ __device__ __forceinline__ void split_round_flat(SplitLDS &L, uint64_t *sorted, 
   const uint32_t v = ((uint32_t)tid < P) ? H[tid] : 0u;
   const uint32_t excl = block_excl_scan(v, L.scan);
   if ((uint32_t)tid < P) {
-    L.offs[tid] = excl;
+    L.meta[tid] = excl;
     uint64_t base = 0;
     if (v) base = atomicAdd((unsigned long long *)&cursors[tid], (unsigned long long)v);
     const uint64_t room = base < seg_cap ? seg_cap - base : 0;
-    L.dbase[tid] = (uint32_t)base;
-    L.c0[tid] = (uint32_t)(base >> 32);
+    L.ab[0][tid] = (uint32_t)base;
+    L.ab[1][tid] = (uint32_t)(base >> 32);
     H[tid] = (uint64_t)v <= room ? v : (uint32_t)room;
     L.hist[buf ^ 1][tid] = 0;
   }
@@ -476,7 +480,7 @@ __device__ __forceinline__ void split_round_flat(SplitLDS &L, uint64_t *sorted, 
   for (int j = 0; j < R; j++) {
     if (br[j] != ~0u) {
       const uint32_t b = br[j] & (PMAX - 1), rank = br[j] >> 10;
-      const uint32_t pos = L.offs[b] + rank;
+      const uint32_t pos = (uint32_t)L.meta[b] + rank;
 #pragma unroll
       for (int w = 0; w < NL; w++) sorted[(size_t)pos * NL + w] = rec[j][w];
     }
@@ -487,9 +491,9 @@ __device__ __forceinline__ void split_round_flat(SplitLDS &L, uint64_t *sorted, 
 #pragma unroll
     for (int w = 0; w < NL; w++) r[w] = sorted[(size_t)i * NL + w];
     const uint32_t b = bucket_of(r);
-    const uint32_t j = i - L.offs[b];
+    const uint32_t j = i - (uint32_t)L.meta[b];
     if (j < H[b]) {
-      const uint64_t base = ((uint64_t)L.c0[b] << 32) | L.dbase[b];
+      const uint64_t base = ((uint64_t)L.ab[1][b] << 32) | L.ab[0][b];
       uint64_t *d = records + ((uint64_t)b * seg_cap + base + j) * NL;
 #pragma unroll
       for (int w = 0; w < NL; w++) d[w] = r[w];

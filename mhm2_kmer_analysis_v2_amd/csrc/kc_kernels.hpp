@@ -162,6 +162,7 @@ struct alignas(16) TileLDS {
   uint32_t codes[G::NGROUP];   // 2-bit codes; u64 word w = {codes[2w+1] (first 16 bases), codes[2w]}
   uint16_t ok[G::NGROUP];      // bit i: base 16g+i may serve as an extension (high quality, ACGT)
   uint32_t gap[G::NWORD + 1];  // bit lp: a read boundary lies between local positions lp-1 and lp
+  uint64_t far_off;            // offsets[first read of the tile + THREADS - 1] (~0 past the end): see tile_encode
 };
 
 __device__ __forceinline__ uint32_t pack4(uint32_t v) {  // 4 ASCII bytes -> 4 codes, first byte highest
@@ -298,6 +299,7 @@ __device__ __forceinline__ void tile_encode(TileLDS<G> &L, const TileRaw<G> &R, 
 #define KC_ENC_STAMP(k)
 #endif
   for (int i = tid; i < G::NWORD + 1; i += G::THREADS) L.gap[i] = 0;
+  if (tid == G::THREADS - 1) L.far_off = R.off;
   tile_barrier();
   KC_ENC_STAMP(0)
   if (!active) {
@@ -371,8 +373,12 @@ __device__ __forceinline__ void tile_encode(TileLDS<G> &L, const TileRaw<G> &R, 
   KC_ENC_STAMP(1)
   if (FMT != FMT_SEQBLOCK) {
     // boundaries from the read offsets (the end of the data is offsets[nreads]); the first one of this thread
-    // came with the prefetch, more only when a tile holds more reads than it has threads
+    // came with the prefetch.  More are loaded only when the tile holds more reads than it has threads, which the
+    // last thread's offset tells everybody (offsets only grow): otherwise the threads that own a boundary would
+    // each wait for one more load just to learn that it lies beyond the tile.
     const int64_t first = T0, last = T0 + G::SPAN + a.k;  // gaps that any window of this tile can contain
+    const uint64_t far = L.far_off;
+    const bool more = far != ~0ULL && (int64_t)far + lo <= last;
     uint64_t off = R.off;
     for (uint64_t r = R.first_read + tid; r <= a.nreads; r += G::THREADS) {
       if (r != R.first_read + tid) off = a.offsets[r];
@@ -382,6 +388,7 @@ __device__ __forceinline__ void tile_encode(TileLDS<G> &L, const TileRaw<G> &R, 
         const int lp = (int)(s - (T0 - PRE));
         atomicOr(&L.gap[lp >> 5], 1u << (lp & 31));
       }
+      if (!more) break;
     }
   } else {
     // start and end of the block are boundaries too

@@ -704,16 +704,29 @@ __global__ __launch_bounds__(WGB) void kc_l2_split_kernel(Geom gm, BucketBufs bb
     __syncthreads();
     const uint32_t n = L.pre[G];
     const uint32_t per_round = WGB * RPOS;
-    uint32_t p = 0;  // segment cursor of this thread (its indices only grow)
-    // the records of the next round are already on their way while this round is split
+    // The records of the next round travel while this round is split.  A record's address needs its chunk id, which
+    // is itself in memory (chain1): all ids of a round are requested first and all records after them, two memory
+    // round trips per round (fetched pairwise, every record load would wait for its own id load: sixteen in a row).
+    uint32_t p_ids = 0, p_rec = 0;  // segment cursors of this thread, one per pass (their indices only grow)
     uint64_t nxt[RPOS][NL];
+    const uint32_t CH1m = (1u << gm.log2CH1) - 1u;
     auto load_round = [&](uint32_t v0) {
+      uint32_t ids[RPOS];
+#pragma unroll
+      for (int j = 0; j < RPOS; j++) {
+        const uint32_t e = v0 + (uint32_t)j * WGB + tid;
+        ids[j] = 0;
+        if (e < n) {
+          while (e >= L.pre[p_ids + 1]) p_ids++;
+          ids[j] = bb.chain1[((size_t)p_ids * gm.P1 + b1) * gm.L1MAX + ((e - L.pre[p_ids]) >> gm.log2CH1)];
+        }
+      }
 #pragma unroll
       for (int j = 0; j < RPOS; j++) {
         const uint32_t e = v0 + (uint32_t)j * WGB + tid;
         if (e < n) {
-          while (e >= L.pre[p + 1]) p++;
-          const uint64_t *src = l1_record<NL>(gm, bb, p, b1, e - L.pre[p]);
+          while (e >= L.pre[p_rec + 1]) p_rec++;
+          const uint64_t *src = bb.rec1 + (((((size_t)p_rec * gm.A1) + ids[j]) << gm.log2CH1) + ((e - L.pre[p_rec]) & CH1m)) * NL;
 #pragma unroll
           for (int w = 0; w < NL; w++) nxt[j][w] = src[w];
         }

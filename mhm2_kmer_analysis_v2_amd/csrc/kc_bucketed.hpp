@@ -592,16 +592,32 @@ __global__ __launch_bounds__(WGB) void kc_l1_records_kernel(const uint64_t *recs
   const uint64_t nrounds = (n + per_round - 1) / per_round;
   uint32_t n_ins = 0;
   int buf = 0;
+  // the records of this workgroup's next round are already on their way while this round is split
+  uint64_t nxt[RPOS][NL];
+  auto load_round = [&](uint64_t rd) {
+#pragma unroll
+    for (int j = 0; j < RPOS; j++) {
+      const uint64_t i = rd * per_round + (uint64_t)j * WGB + tid;
+      if (rd < nrounds && i < n) {
+#pragma unroll
+        for (int w = 0; w < NL; w++) nxt[j][w] = recs[i * NL + w];
+      }
+    }
+  };
+  load_round(blockIdx.x);
   for (uint64_t rd = blockIdx.x; rd < nrounds; rd += gridDim.x) {
     uint64_t rec[RPOS][NL];
     uint32_t br[RPOS];
+#pragma unroll
+    for (int j = 0; j < RPOS; j++)
+#pragma unroll
+      for (int w = 0; w < NL; w++) rec[j][w] = nxt[j][w];
+    load_round(rd + gridDim.x);
 #pragma unroll
     for (int j = 0; j < RPOS; j++) {
       const uint64_t i = rd * per_round + (uint64_t)j * WGB + tid;
       br[j] = ~0u;
       if (i < n) {
-#pragma unroll
-        for (int w = 0; w < NL; w++) rec[j][w] = recs[i * NL + w];
         if (CP) rec[j][0] = cp_mix_rec(rec[j][0], gm);
         const uint32_t b = CP ? cp_b1(rec[j][0], gm) : hash_b1(rec_hash<NL>(rec[j]), gm);
         const uint32_t rank = atomicAdd(&L.sp.hist[buf][b], 1u);

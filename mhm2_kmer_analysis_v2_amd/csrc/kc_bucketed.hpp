@@ -726,29 +726,26 @@ __global__ __launch_bounds__(WGB) void kc_l2_split_kernel(Geom gm, BucketBufs bb
     uint32_t p_ids = 0, p_rec = 0;  // segment cursors of this thread, one per pass (their indices only grow)
     uint64_t nxt[RPOS][NL];
     const uint32_t CH1m = (1u << gm.log2CH1) - 1u;
-    auto load_round = [&](uint32_t v0) {
+    // no branches around the loads (a lane past the end re-reads the bucket's last record): a load inside a
+    // conditional block is waited for at the end of that block
+    auto load_round = [&](uint32_t v0) {  // n > 0
       uint32_t ids[RPOS];
 #pragma unroll
       for (int j = 0; j < RPOS; j++) {
-        const uint32_t e = v0 + (uint32_t)j * WGB + tid;
-        ids[j] = 0;
-        if (e < n) {
-          while (e >= L.pre[p_ids + 1]) p_ids++;
-          ids[j] = bb.chain1[((size_t)p_ids * gm.P1 + b1) * gm.L1MAX + ((e - L.pre[p_ids]) >> gm.log2CH1)];
-        }
+        const uint32_t e = min(v0 + (uint32_t)j * WGB + tid, n - 1u);
+        while (e >= L.pre[p_ids + 1]) p_ids++;
+        ids[j] = bb.chain1[((size_t)p_ids * gm.P1 + b1) * gm.L1MAX + ((e - L.pre[p_ids]) >> gm.log2CH1)];
       }
 #pragma unroll
       for (int j = 0; j < RPOS; j++) {
-        const uint32_t e = v0 + (uint32_t)j * WGB + tid;
-        if (e < n) {
-          while (e >= L.pre[p_rec + 1]) p_rec++;
-          const uint64_t *src = bb.rec1 + (((((size_t)p_rec * gm.A1) + ids[j]) << gm.log2CH1) + ((e - L.pre[p_rec]) & CH1m)) * NL;
+        const uint32_t e = min(v0 + (uint32_t)j * WGB + tid, n - 1u);
+        while (e >= L.pre[p_rec + 1]) p_rec++;
+        const uint64_t *src = bb.rec1 + (((((size_t)p_rec * gm.A1) + ids[j]) << gm.log2CH1) + ((e - L.pre[p_rec]) & CH1m)) * NL;
 #pragma unroll
-          for (int w = 0; w < NL; w++) nxt[j][w] = src[w];
-        }
+        for (int w = 0; w < NL; w++) nxt[j][w] = src[w];
       }
     };
-    load_round(0);
+    if (n) load_round(0);
     int buf = 0;
     for (uint32_t v0 = 0; v0 < n; v0 += per_round) {
       uint64_t rec[RPOS][NL];

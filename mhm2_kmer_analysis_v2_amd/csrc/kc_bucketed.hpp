@@ -594,17 +594,16 @@ __global__ __launch_bounds__(WGB) void kc_l1_records_kernel(const uint64_t *recs
   int buf = 0;
   // the records of this workgroup's next round are already on their way while this round is split
   uint64_t nxt[RPOS][NL];
-  auto load_round = [&](uint64_t rd) {
+  auto load_round = [&](uint64_t rd) {  // n > 0; no branches around the loads (a lane past the end re-reads the last record)
 #pragma unroll
     for (int j = 0; j < RPOS; j++) {
-      const uint64_t i = rd * per_round + (uint64_t)j * WGB + tid;
-      if (rd < nrounds && i < n) {
+      uint64_t i = rd * per_round + (uint64_t)j * WGB + tid;
+      i = i < n ? i : n - 1;
 #pragma unroll
-        for (int w = 0; w < NL; w++) nxt[j][w] = recs[i * NL + w];
-      }
+      for (int w = 0; w < NL; w++) nxt[j][w] = recs[i * NL + w];
     }
   };
-  load_round(blockIdx.x);
+  if (n) load_round(blockIdx.x);
   for (uint64_t rd = blockIdx.x; rd < nrounds; rd += gridDim.x) {
     uint64_t rec[RPOS][NL];
     uint32_t br[RPOS];

@@ -243,9 +243,9 @@ def kmer_to_string(words, k):
     return "".join("ACGT"[(int(words[i // 32]) >> (2 * (31 - (i % 32)))) & 3] for i in range(k))
 
 
-def analyze_kmers(kmer_len, qual_offset, bases, quals, offsets, dmin_thres=2, device=0, max_elems=0):
+def analyze_kmers(kmer_len, qual_offset, bases, quals, offsets, dmin_thres=2, device=0, max_elems=0, tuning=None):
     """analyze_kmers (src/kcount/kcount.cpp:142-161) for one shard: returns sorted results and stats."""
-    with KmerCounter(kmer_len, qual_offset, dmin_thres, device=device, max_elems=max_elems) as kc:
+    with KmerCounter(kmer_len, qual_offset, dmin_thres, device=device, max_elems=max_elems, tuning=tuning) as kc:
         kc.submit_reads(bases, quals, offsets)
         kc.flush()
         res = kc.sorted_results()

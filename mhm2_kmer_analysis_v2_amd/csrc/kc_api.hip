@@ -1267,7 +1267,13 @@ static int bk_finalize(kc_ctx *c) {
   // Output positions are handed out in blocks per workgroup (OutBufs::block); the unused tails are closed afterwards.
   // The arrays need room for one block per workgroup beyond the entries themselves.
   const uint32_t max_wg = 2u * (uint32_t)c->num_cus;
-  const uint32_t block = max_wg < PLAN_RUNS ? 8192u : 0u;
+  // blocks of up to 8192 entries, smaller when few results are expected (all the tails together stay within a
+  // quarter of the estimate)
+  uint32_t block = 0;
+  if (max_wg < PLAN_RUNS) {
+    block = 64;
+    while (block < 8192u && (uint64_t)block * 2 * max_wg * 4 <= cap) block *= 2;
+  }
   if (block && !c->d_out_plan) {
     HIPCHK(hipMalloc((void **)&c->d_out_plan, (PLAN_WORDS + 2 * (size_t)max_wg) * 8));
   }

@@ -328,6 +328,23 @@ def test_overflow_paths_are_exact(k, tuning):
     assert st["num_unique"] == wst["unique"] and st["num_purged"] == wst["purged"] and st["sum_counts"] == wst["sum_counts"]
 
 
+def test_result_arrays_grow_when_the_estimate_was_too_small():
+    # max_elems far below the truth: the first vote/purge pass finds the result arrays too small (its blocks of
+    # output positions run past them) and is run again with room for what it counted
+    k = 21
+    rng = np.random.default_rng(77)
+    reads, quals = random_reads(rng, 24000, min_len=100, max_len=160, genome_len=150000, err=0.005)
+    b, q, offs = arrays(reads, quals)
+    want, _, wst = oracle_run(b, q, offs, k)
+    assert len(want[1]) > 110000  # more survivors than the first allocation holds
+    with pkg.KmerCounter(k, max_elems=2000, max_kmers_buffered=1 << 23, tuning=dict(p1=64, p2=64, slots=2048)) as kc:
+        kc.submit_reads(b, q, offs)
+        got = kc.sorted_results()
+        st = kc.stats()
+    assert_same(got, want)
+    assert st["num_unique"] == wst["unique"] and st["num_dropped"] == 0
+
+
 def test_exhausted_overflow_list_is_an_error_not_a_loss():
     reads, quals = _reads_for_overflow()
     b, q, offs = arrays(reads, quals)

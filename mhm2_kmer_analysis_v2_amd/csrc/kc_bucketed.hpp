@@ -456,10 +456,10 @@ __global__ __launch_bounds__(WGB) void kc_l1_reads_kernel(ExtractArgs a, Geom gm
 // Same tile extraction and LDS multisplit as level 1, with the owner shard as the bucket and the caller's
 // per-shard segments as destinations: one global cursor bump per shard and round (a handful of atomics per
 // 8 Ki records) instead of one per wave and shard.
-template <int NL, int R, class BucketFn>
-__device__ __forceinline__ void split_round_flat(SplitLDS &L, uint64_t *sorted, int buf, uint32_t P, const uint64_t (&rec)[R][NL],
-                                                 const uint32_t (&br)[R], uint64_t *records, uint64_t seg_cap, uint64_t *cursors,
-                                                 uint64_t *overflow_flag, BucketFn bucket_of) {
+template <int NL, int R>
+__device__ __forceinline__ void split_round_flat(SplitLDS &L, uint64_t *sorted, uint16_t *sbucket, int buf, uint32_t P,
+                                                 const uint64_t (&rec)[R][NL], const uint32_t (&br)[R], uint64_t *records, uint64_t seg_cap,
+                                                 uint64_t *cursors, uint64_t *overflow_flag) {
   const int tid = threadIdx.x;
   uint32_t *H = L.hist[buf];
   const uint32_t v = ((uint32_t)tid < P) ? H[tid] : 0u;
@@ -483,6 +483,7 @@ __device__ __forceinline__ void split_round_flat(SplitLDS &L, uint64_t *sorted, 
       const uint32_t pos = (uint32_t)L.meta[b] + rank;
 #pragma unroll
       for (int w = 0; w < NL; w++) sorted[(size_t)pos * NL + w] = rec[j][w];
+      sbucket[pos] = (uint16_t)b;  // the owner shard travels with the staged record: no second hash at copy-out
     }
   }
   lds_barrier();
@@ -490,7 +491,7 @@ __device__ __forceinline__ void split_round_flat(SplitLDS &L, uint64_t *sorted, 
     uint64_t r[NL];
 #pragma unroll
     for (int w = 0; w < NL; w++) r[w] = sorted[(size_t)i * NL + w];
-    const uint32_t b = bucket_of(r);
+    const uint32_t b = sbucket[i];
     const uint32_t j = i - (uint32_t)L.meta[b];
     if (j < H[b]) {
       const uint64_t base = ((uint64_t)L.ab[1][b] << 32) | L.ab[0][b];
@@ -508,6 +509,7 @@ __global__ __launch_bounds__(WGB) void kc_bin_reads_kernel(ExtractArgs a, uint64
   extern __shared__ __align__(16) uint8_t smem[];
   L1LDS &L = *reinterpret_cast<L1LDS *>(smem);
   uint64_t *sorted = reinterpret_cast<uint64_t *>(smem + ((sizeof(L1LDS) + 15) & ~size_t(15)));
+  uint16_t *sbucket = reinterpret_cast<uint16_t *>(smem + ((sizeof(L1LDS) + 15) & ~size_t(15)) + Rnd<NL>::STAGE_READS);
   constexpr int RPOS = Rnd<NL>::RPOS_READS;
   const int tid = threadIdx.x;
   const uint32_t P = a.rank_n;
@@ -547,25 +549,28 @@ __global__ __launch_bounds__(WGB) void kc_bin_reads_kernel(ExtractArgs a, uint64
         const bool valid = run_kmer<NL>(run, j, lp0, a.k, rec[j], h, P, a.reference_owner, &owner) && active;
         if (j + 1 < RPOS) run_advance<NL>(run, j, lp0, a.k);
         br[j] = ~0u;
-        if (valid) {
-          const uint32_t b = P > 1 ? owner : 0u;
+        const uint32_t b = P > 1 ? owner : 0u;
+        if (P <= 16) {
+          // few shards: the lanes of a wave that go to the same one take their ranks from one LDS add (64 separate
+          // adds to a handful of words would be serialised)
+          for (uint32_t d = 0; d < P; d++) {
+            const bool mine = valid && b == d;
+            const uint64_t m = __ballot(mine);
+            if (m) {  // wave-uniform
+              const int leader = __ffsll((long long)m) - 1;
+              uint32_t base = 0;
+              if ((int)lane_id() == leader) base = atomicAdd(&L.sp.hist[buf][d], (uint32_t)__popcll(m));
+              base = __shfl(base, leader);
+              if (mine) br[j] = d | ((base + (uint32_t)__popcll(m & ((1ULL << lane_id()) - 1ULL))) << 10);
+            }
+          }
+        } else if (valid) {
           const uint32_t rank = atomicAdd(&L.sp.hist[buf][b], 1u);
           br[j] = b | (rank << 10);
         }
       }
       lds_barrier();
-      split_round_flat<NL, RPOS>(L.sp, sorted, buf, P, rec, br, a.records, a.seg_capacity, ctrs + CTR_BIN0, ctrs + CTR_OVERFLOW,
-                                 [&](const uint64_t (&r)[NL]) -> uint32_t {
-                                   if (P <= 1) return 0u;
-                                   uint64_t key[NL];
-#pragma unroll
-                                   for (int w = 0; w < NL; w++) key[w] = r[w];
-                                   key[NL - 1] &= ~KC_EXT_MASK;
-                                   if (!a.reference_owner) return kc_owner_of_hash(kc_hash<NL>(key), P);
-                                   uint64_t rc[NL];
-                                   kc_revcomp<NL>(key, a.k, rc);
-                                   return kc_reference_owner<NL>(key, rc, a.k, P);
-                                 });
+      split_round_flat<NL, RPOS>(L.sp, sorted, sbucket, buf, P, rec, br, a.records, a.seg_capacity, ctrs + CTR_BIN0, ctrs + CTR_OVERFLOW);
       buf ^= 1;
     }
   }

@@ -1312,6 +1312,12 @@ static int bk_finalize(kc_ctx *c) {
     }
     rc = sync_ctrs(c);
     if (rc) return rc;
+#ifdef KC_STAMPS
+    (void)sync_cb(c);
+    fprintf(stderr, "count kernel cycles (thread 0, summed over workgroups): zero %llu insert %llu satscan %llu vote %llu write %llu\n",
+            (unsigned long long)c->h_cb[8], (unsigned long long)c->h_cb[9], (unsigned long long)c->h_cb[10],
+            (unsigned long long)c->h_cb[11], (unsigned long long)c->h_cb[12]);
+#endif
     if (block) {
       rc = sync_cb(c);
       if (rc) return rc;
@@ -1320,12 +1326,6 @@ static int bk_finalize(kc_ctx *c) {
       cap = c->h_ctrs[CTR_OUT] + slack;
       continue;
     }
-#ifdef KC_STAMPS
-    (void)sync_cb(c);
-    fprintf(stderr, "count kernel cycles (thread 0, summed over workgroups): zero %llu insert %llu satscan %llu vote %llu write %llu\n",
-            (unsigned long long)c->h_cb[8], (unsigned long long)c->h_cb[9], (unsigned long long)c->h_cb[10],
-            (unsigned long long)c->h_cb[11], (unsigned long long)c->h_cb[12]);
-#endif
     if (c->h_ctrs[CTR_OUT] <= c->out_cap) break;
     cap = c->h_ctrs[CTR_OUT];  // the pass only counted past the end: run it again with exactly enough room
   }

@@ -1142,13 +1142,18 @@ __global__ __launch_bounds__(WGB, 8) void kc_count_kernel(Geom gm, BucketBufs bb
     const uint32_t nocc = T.nocc;
     // S7 vote + S8 purge over the region's entries; survivors get a rank.  A k-mer seen more than 65535 times may
     // have overflowed a packed 16-bit extension counter: the region then goes to the global table instead.
-    for (uint32_t e = tid; e < nocc; e += WGB) {
-      const uint32_t s = tb.occ[e];
-      uint32_t packed = ~0u;
-      const uint32_t count = tb.cnt[s];
+    // (every lane walks the loop: the survivors of a wave take their ranks from ONE add to the region's counter, and
+    // their counts are summed in the wave first -- a thousand single adds to one LDS word would be serialised)
+    for (uint32_t e0 = 0; e0 < nocc; e0 += WGB) {
+      const uint32_t e = e0 + tid;
+      const bool live = e < nocc;
+      const uint32_t s = live ? tb.occ[e] : 0u;
+      const uint32_t count = live ? tb.cnt[s] : 0u;
       if (count > KC_COUNT_MAX) T.fail = 1;
+      bool keep = false;
+      uint32_t l = 0, rr = 0;
       if (DUMP) {
-        packed = count | (atomicAdd(&T.nout, 1u) << 20);
+        keep = live;
       } else if (count >= 2) {
         uint32_t lc[4], rc[4];
 #pragma unroll
@@ -1156,14 +1161,25 @@ __global__ __launch_bounds__(WGB, 8) void kc_count_kernel(Geom gm, BucketBufs bb
           lc[x] = ext_get(tb.ext, SM, s, 0, x);
           rc[x] = ext_get(tb.ext, SM, s, 1, x);
         }
-        const uint32_t l = vote_ext(lc, count, dmin_thres), rr = vote_ext(rc, count, dmin_thres);
-        if (l < 4u && rr < 4u) {
-          const uint32_t rank = atomicAdd(&T.nout, 1u);
-          packed = (count & 0xFFFFu) | (l << 16) | (rr << 18) | (rank << 20);
-          atomicAdd(&T.sum, (unsigned long long)count);
+        l = vote_ext(lc, count, dmin_thres);
+        rr = vote_ext(rc, count, dmin_thres);
+        keep = l < 4u && rr < 4u;
+      }
+      const uint64_t m = __ballot(keep);
+      uint32_t wsum = keep ? count : 0u;  // < 2^16 each
+      for (int o = 32; o > 0; o >>= 1) wsum += __shfl_down(wsum, o);
+      if (m) {  // wave-uniform
+        const int leader = __ffsll((long long)m) - 1;
+        uint32_t base = 0;
+        if ((int)lane_id() == leader) base = atomicAdd(&T.nout, (uint32_t)__popcll(m));
+        base = __shfl(base, leader);
+        if (lane_id() == 0 && !DUMP) atomicAdd(&T.sum, (unsigned long long)wsum);
+        if (keep) {
+          const uint32_t rank = base + (uint32_t)__popcll(m & ((1ULL << lane_id()) - 1ULL));
+          tb.cnt[s] = DUMP ? (count | (rank << 20)) : ((count & 0xFFFFu) | (l << 16) | (rr << 18) | (rank << 20));
         }
       }
-      tb.cnt[s] = packed;
+      if (live && !keep) tb.cnt[s] = ~0u;
     }
     __syncthreads();
     if (T.fail) {  // more distinct k-mers than slots, or a saturated k-mer: the whole region goes to the global table instead

@@ -897,58 +897,6 @@ __device__ __forceinline__ void occ_push(uint32_t *nocc, uint16_t *occ, bool is_
   }
 }
 
-template <int NL>
-__device__ __forceinline__ void lds_insert(CountLDS<NL> &T, const CountTab &tb, const uint64_t (&rec)[NL], bool valid) {
-  const uint32_t SM = tb.S, S = tb.S;
-  uint64_t key[NL];
-#pragma unroll
-  for (int j = 0; j < NL; j++) key[j] = rec[j];
-  const uint32_t le = (uint32_t)(rec[NL - 1] & 7u), re = (uint32_t)((rec[NL - 1] >> 3) & 7u);
-  key[NL - 1] &= ~KC_EXT_MASK;
-  uint32_t s = hash_slot(kc_hash<NL>(key), S);
-  unsigned long long *claim = (unsigned long long *)&tb.keys[(NL - 1) * SM];
-  uint32_t probes = 0;
-  bool is_new = false;
-  if (valid)
-  for (;;) {
-    unsigned long long cur = __hip_atomic_load(&claim[s], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
-    if (cur == KEY_EMPTY) {
-      cur = atomicCAS(&claim[s], (unsigned long long)KEY_EMPTY, (unsigned long long)(NL == 1 ? key[0] : KEY_BUSY));
-      if (cur == KEY_EMPTY) {
-        if (NL > 1) {
-#pragma unroll
-          for (int j = 0; j < NL - 1; j++) tb.keys[j * SM + s] = key[j];
-          __threadfence_block();
-          atomicExch(&claim[s], (unsigned long long)key[NL - 1]);
-        }
-        is_new = true;
-        break;
-      }
-    }
-    if (NL > 1 && cur == KEY_BUSY) continue;  // its owner publishes within this loop trip of its wave
-    if (cur == key[NL - 1]) {
-      bool same = true;
-      if (NL > 1) {
-#pragma unroll
-        for (int j = 0; j < NL - 1; j++) same &= (tb.keys[j * SM + s] == key[j]);
-      }
-      if (same) break;
-    }
-    s = (s + 1) & (S - 1u);
-    if (++probes >= S) {  // every slot holds some other k-mer
-      T.fail = 1;
-      valid = false;
-      break;
-    }
-  }
-  (void)is_new;
-  if (valid) {
-    atomicAdd(&tb.cnt[s], 1u);
-    if (le < 4u) ext_bump(tb.ext, SM, s, 0, le);
-    if (re < 4u) ext_bump(tb.ext, SM, s, 1, re);
-  }
-}
-
 // One-word keys: the probe written for a low instruction count.  The region kernels are bound by instruction
 // issue (PMC: as many scalar as vector instructions, almost no idle LDS or HBM), and the lanes of a wave probe in
 // lock step, so every trip of this loop is paid by all 64 lanes.  Predicates are kept as 0/1 integers in vector
@@ -990,6 +938,41 @@ __device__ __forceinline__ uint32_t lds_probe32(uint32_t *claim, uint32_t Sm1, u
     act = miss;
     slot = (slot + miss) & Sm1;
     if (++trips > Sm1 + 1) {  // every slot holds some other k-mer (wave-uniform exit)
+      failed |= act;
+      break;
+    }
+  } while (__any(act));
+  return slot;
+}
+
+// Several-word keys, same style: the last word is the claim word (EMPTY -> BUSY -> the key's last word), the others
+// are written between the claim and its publication.  A lane that finds BUSY tries the same slot again (its owner
+// publishes within this same trip of its own wave); a lane that finds its last word compares the other words.
+template <int NL>
+__device__ __forceinline__ uint32_t lds_probeN(const CountTab &tb, const uint64_t (&key)[NL], uint32_t slot, uint32_t valid, uint32_t &failed) {
+  const uint32_t SM = tb.S, Sm1 = tb.S - 1u;
+  unsigned long long *claim = (unsigned long long *)&tb.keys[(NL - 1) * SM];
+  const unsigned long long klast = key[NL - 1];
+  uint32_t act = valid, trips = 0;
+  do {
+    unsigned long long old = klast;  // a lane that is done looks like a hit on its own key below
+    if (act) old = atomicCAS(&claim[slot], (unsigned long long)KEY_EMPTY, (unsigned long long)KEY_BUSY);
+    const uint32_t won = (act && old == KEY_EMPTY) ? 1u : 0u;
+    if (won) {
+#pragma unroll
+      for (int j = 0; j < NL - 1; j++) tb.keys[j * SM + slot] = key[j];
+      __threadfence_block();  // the words are in place before the claim word says so
+      atomicExch(&claim[slot], klast);
+    }
+    uint32_t same = old == klast ? 1u : 0u;
+#pragma unroll
+    for (int j = 0; j < NL - 1; j++) same &= (tb.keys[j * SM + slot] == key[j]) ? 1u : 0u;
+    const uint32_t busy = old == KEY_BUSY ? 1u : 0u;
+    const uint32_t hit = won | same;
+    const uint32_t miss = act & ~hit & ~busy & 1u;
+    act &= ~hit & 1u;
+    slot = (slot + miss) & Sm1;
+    if (++trips > 4u * (Sm1 + 1u)) {  // every slot holds some other k-mer (wave-uniform exit)
       failed |= act;
       break;
     }
@@ -1125,8 +1108,24 @@ __global__ __launch_bounds__(WGB, 8) void kc_count_kernel(Geom gm, BucketBufs bb
         }
         if (failed) T.fail = 1;
       } else {
+        uint32_t failed = 0;
 #pragma unroll
-        for (int j = 0; j < BATCH; j++) lds_insert<NL>(T, tb, rec[j], (i0 + (uint32_t)j * WGB + tid) < n);
+        for (int j = 0; j < BATCH; j++) {
+          const uint32_t v = (i0 + (uint32_t)j * WGB + tid) < n ? 1u : 0u;
+          if (!__any(v)) continue;  // past the end of the region for the whole wave
+          uint64_t key[NL];
+#pragma unroll
+          for (int w = 0; w < NL; w++) key[w] = rec[j][w];
+          const uint32_t le = (uint32_t)(rec[j][NL - 1] & 7u), re = (uint32_t)((rec[j][NL - 1] >> 3) & 7u);
+          key[NL - 1] &= ~KC_EXT_MASK;
+          const uint32_t s = lds_probeN<NL>(tb, key, hash_slot(kc_hash<NL>(key), S), v, failed);
+          if (v && !(failed & 1u)) {
+            atomicAdd(&tb.cnt[s], 1u);
+            if (le < 4u) ext_bump(tb.ext, SM, s, 0, le);
+            if (re < 4u) ext_bump(tb.ext, SM, s, 1, re);
+          }
+        }
+        if (failed) T.fail = 1;
       }
     }
     __syncthreads();

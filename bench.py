@@ -31,7 +31,7 @@ def parse_args():
     ap.add_argument("--warmup", type=int, default=1)
     ap.add_argument("--reads", type=int, default=50_000_000, help="reads per GPU (150 bp each)")
     ap.add_argument("--k", type=int, default=21)
-    ap.add_argument("--block-reads", type=int, default=4_000_000, help="N>1: reads per exchange block")
+    ap.add_argument("--block-reads", type=int, default=8_000_000, help="N>1: reads per exchange block")
     ap.add_argument("--cpu-sample-reads", type=int, default=1_000_000, help="reads timed through the CPU oracle (0 = skip)")
     ap.add_argument("--check", action="store_true", help="size-independent result checks after the timed region")
     ap.add_argument("--table-path", action="store_true", help="A/B: force the global-table insert path instead of the bucketed one")

@@ -23,11 +23,12 @@ def exchange_counts(send_counts, group=None):
 def start_exchange(send, send_counts, recv_counts, seg_capacity, num_longs, recv=None, group=None):
     """Begin the all-to-all-v of one block.  send: int64 tensor laid out as world segments of seg_capacity records
     (num_longs words each), the first send_counts[d] records of segment d being valid.  Returns
-    (works, recv tensor, n_received): the received records packed back to back once every work has been waited for."""
+    (works, recv tensor, n_received): the records received from the OTHER ranks packed back to back once every work
+    has been waited for.  The rank's own share stays where it is: local_share(send, send_counts, ...) is its view."""
     world = dist.get_world_size(group)
     sc = [int(x) for x in send_counts.tolist()]
     rc = [int(x) for x in recv_counts.tolist()]
-    total = sum(rc)
+    total = sum(rc) - rc[dist.get_rank(group)]  # what arrives from the other ranks
     if recv is None or recv.numel() < max(total, 1) * num_longs:
         recv = torch.empty(max(total, 1) * num_longs, dtype=send.dtype, device=send.device)
     # all-to-all-v as one group of point-to-point transfers (RCCL: a single ncclGroup of
@@ -39,11 +40,10 @@ def start_exchange(send, send_counts, recv_counts, seg_capacity, num_longs, recv
     for d in range(world):
         base = d * seg_capacity * num_longs
         src = send[base:base + sc[d] * num_longs]
+        if d == me:
+            continue  # this rank's own share never travels: the caller inserts it straight from `send` (local_share)
         dst = recv[pos:pos + rc[d] * num_longs]
         pos += rc[d] * num_longs
-        if d == me:
-            dst.copy_(src)
-            continue
         peer = dist.get_global_rank(group, d) if group is not None else d
         if rc[d]:
             ops.append(dist.P2POp(dist.irecv, dst, peer, group))
@@ -53,12 +53,21 @@ def start_exchange(send, send_counts, recv_counts, seg_capacity, num_longs, recv
     return works, recv, total
 
 
+def local_share(send, send_counts, seg_capacity, num_longs, group=None):
+    """The records this rank keeps for itself: a view of its own segment of `send` and their number."""
+    me = dist.get_rank(group)
+    n = int(send_counts[me])
+    base = me * seg_capacity * num_longs
+    return send[base:base + n * num_longs], n
+
+
 def exchange_records(send, send_counts, recv_counts, seg_capacity, num_longs, recv=None, group=None):
-    """Blocking form of start_exchange."""
+    """Blocking form of start_exchange: returns (received from the others, their number, own share, its number)."""
     works, recv, total = start_exchange(send, send_counts, recv_counts, seg_capacity, num_longs, recv, group)
     for w in works:
         w.wait()
-    return recv, total
+    own, n_own = local_share(send, send_counts, seg_capacity, num_longs, group)
+    return recv, total, own, n_own
 
 
 class ShardedKmerAnalysis:
@@ -86,14 +95,16 @@ class ShardedKmerAnalysis:
     def _complete(self):
         if self.pending is None:
             return 0
-        works, recv, n = self.pending
+        works, recv, n, own, n_own = self.pending
         self.pending = None
+        if n_own:
+            self.insert(own, n_own)  # straight from the send buffer (reused two blocks later at the earliest)
         for w in works:
             w.wait()
         if n:
             self.insert(recv, n)
-        self.received += n
-        return n
+        self.received += n + n_own
+        return n + n_own
 
     def add_block(self, block):
         b = self.i % 2
@@ -101,11 +112,13 @@ class ShardedKmerAnalysis:
         counts = self.extract(block, self.send[b], self.seg)
         sc = torch.as_tensor([int(c) for c in counts], dtype=torch.int64, device=self.device)
         rc = exchange_counts(sc, self.group)
-        works, self.recv[b], n = start_exchange(self.send[b], sc.cpu(), rc.cpu(), self.seg, self.nl, self.recv[b], self.group)
+        sc_host = sc.cpu()
+        works, self.recv[b], n = start_exchange(self.send[b], sc_host, rc.cpu(), self.seg, self.nl, self.recv[b], self.group)
+        own, n_own = local_share(self.send[b], sc_host, self.seg, self.nl, self.group)
         self._complete()  # the previous block: its transfer has had this block's extraction to finish
-        self.pending = (works, self.recv[b], n)
-        self.sent += int(sc.sum())
-        return n
+        self.pending = (works, self.recv[b], n, own, n_own)
+        self.sent += int(sc_host.sum())
+        return n + n_own
 
     def finish(self):
         """Wait for and insert the last block in flight (call before finalize)."""

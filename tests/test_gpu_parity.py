@@ -78,7 +78,8 @@ def test_synthetic_arctic_shaped_reads_match_oracle():
         assert st["num_unique"] == wst["unique"] and st["sum_counts"] == wst["sum_counts"]
 
 
-def test_device_resident_input_and_unaligned_pointers():
+@pytest.mark.parametrize("tuning", [None, PATHS["compact"]], ids=["default", "compact"])
+def test_device_resident_input_and_unaligned_pointers(tuning):
     import torch
     k = 21
     rng = np.random.default_rng(7)
@@ -92,12 +93,13 @@ def test_device_resident_input_and_unaligned_pointers():
         dq[shift_q:shift_q + len(q)] = torch.from_numpy(q).cuda()
         doff = torch.from_numpy(offs.astype(np.int64)).cuda()
         torch.cuda.synchronize()
-        with pkg.KmerCounter(k) as kc:
+        with pkg.KmerCounter(k, tuning=tuning) as kc:
             kc.submit_reads(db[shift_b:], dq[shift_q:], doff, nreads=len(reads))
             assert_same(kc.sorted_results(), want)
 
 
-def test_seq_block_format_matches_oracle():
+@pytest.mark.parametrize("tuning", [None, PATHS["compact"]], ids=["default", "compact"])
+def test_seq_block_format_matches_oracle(tuning):
     # ParseAndPackGPUDriver::process_seq_block's input: case-masked reads joined by '_'
     k = 21
     rng = np.random.default_rng(8)
@@ -108,7 +110,7 @@ def test_seq_block_format_matches_oracle():
     for r, ql in zip(reads, quals):
         masked.append("".join(c.lower() if ord(x) < 33 + 20 else c for c, x in zip(r, ql)))
     for block in ("_".join(masked), "_".join(masked) + "_", "_" + "__".join(masked)):
-        with pkg.KmerCounter(k) as kc:
+        with pkg.KmerCounter(k, tuning=tuning) as kc:
             kc.submit_seq_block(block.encode())
             got = kc.sorted_results()
             st = kc.stats()
@@ -140,7 +142,8 @@ def test_sharded_flow_on_one_gpu():
         b, q, offs = arrays(reads, quals)
         want, _, wst = oracle_run(b, q, offs, k)
         R = 3
-        shards = [pkg.KmerCounter(k, rank_me=r, rank_n=R) for r in range(R)]
+        # k=21: the shards use the benchmark's fan-outs, i.e. compact records (mixed on arrival)
+        shards = [pkg.KmerCounter(k, rank_me=r, rank_n=R, tuning=PATHS["compact"] if k == 21 else None) for r in range(R)]
         seg = int(wst["kmers_inserted"])  # worst case: everything to one shard
         recs = torch.zeros(R * seg * nl, dtype=torch.int64, device="cuda")
         # each "rank" parses a third of the reads and bins for all owners

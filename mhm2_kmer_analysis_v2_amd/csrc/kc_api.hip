@@ -458,14 +458,15 @@ static int bk_init(kc_ctx *c) {
   const uint64_t bcap = c->cfg.max_kmers_buffered ? c->cfg.max_kmers_buffered : (1ULL << 26);
   const double est = c->cfg.max_elems ? (double)c->cfg.max_elems : 0.35 * (double)bcap;  // 1/depth(4) + error share, kmer_dht.cpp:126-131
   const uint32_t smax = count_smax(c->nl);
-  // Region tables are meant to run at about 0.6 load: fewer, fuller regions amortise the per-region costs (barriers,
-  // the exposed latency of the first loads and of the output reservation) better than more, emptier ones.
+  // Region tables are meant to run at about 0.4 load: the lanes of a wave probe in lock step, so a wave pays for its
+  // longest probe, and the count kernel's time grows steeply with the load (measured: 1.6x from 0.4 to 0.6), more
+  // than the per-region costs (barriers, the exposed latency of the first loads) shrink with fewer, fuller regions.
   // Half-size tables let two region workgroups share a CU (one's barriers and scans overlap the other's inserts:
-  // measured 10 % faster counting), so prefer them while 2^20 regions still cover the expected distinct k-mers.
+  // measured 10 % faster counting), so prefer them while 2^20 regions of them stay under 0.55 load.
   g.S = t.slots ? std::min(std::max(t.slots, 16u), smax) : smax;
   while (g.S & (g.S - 1)) g.S &= g.S - 1;  // power of two (round down)
-  const double target_load = 0.6;
-  if (!t.slots && est / (target_load * (g.S / 2)) + 1 <= (double)(1u << 20)) g.S /= 2;
+  const double target_load = 0.4;
+  if (!t.slots && est <= 0.55 * (double)(1u << 20) * (g.S / 2)) g.S /= 2;
   const uint64_t regions_needed = std::min<uint64_t>((uint64_t)(est / (target_load * g.S)) + 1, 1ULL << 20);
   // the two fan-outs multiply to the number of regions; any value up to 1024 each (the hash fields are mapped by
   // multiply-shift), level 1 the smaller one because it holds fewer records per round

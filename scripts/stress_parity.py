@@ -1,0 +1,57 @@
+"""Randomised parity sweep on the GPU against the oracle: random k, geometry, read shapes.
+python scripts/stress_parity.py [cases] [seed] [scale]"""
+import os, sys
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+sys.path.insert(0, os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "tests"))
+import numpy as np
+import mhm2_kmer_analysis_v2_amd as pkg
+from oracle import cpu_oracle as O
+from helpers import random_reads
+
+cases = int(sys.argv[1]) if len(sys.argv) > 1 else 40
+seed = int(sys.argv[2]) if len(sys.argv) > 2 else 1
+scale = int(sys.argv[3]) if len(sys.argv) > 3 else 1  # multiplies the number of reads and the genome length
+rng = np.random.default_rng(seed)
+KS = [11, 13, 15, 17, 19, 21, 23, 25, 27, 29, 33, 47, 51, 61, 65, 77, 93]  # k % 32 in {30, 31} is rejected by the library
+bad = 0
+for c in range(cases):
+    k = int(rng.choice(KS))
+    nreads = int(rng.integers(200, 6000)) * scale
+    genome = int(rng.integers(500, 60000)) * scale
+    reads, quals = random_reads(rng, nreads, min_len=int(rng.integers(1, k + 3)), max_len=k + int(rng.integers(2, 200)),
+                                genome_len=genome, err=float(rng.choice([0.0, 0.005, 0.03])), n_rate=float(rng.choice([0.0, 0.01, 0.1])))
+    b, q, offs = O.reads_to_arrays(reads, quals)
+    o = O.Oracle(k, nranks=int(rng.integers(1, 5)), nthreads=8)
+    o.add_reads(b, q, offs)
+    want = o.finalize()
+    o.close()
+    la, lb = int(rng.integers(1, 11)), int(rng.integers(1, 11))
+    tuning = rng.choice(["auto", "pow2", "odd", "tiny-chunks", "wide"])
+    t = None
+    if tuning == "pow2":
+        t = dict(writers=int(rng.integers(1, 9)), p1=1 << la, p2=1 << lb, slots=int(rng.choice([256, 1024, 2048, 4096])))
+    elif tuning == "odd":
+        t = dict(writers=int(rng.integers(1, 9)), p1=int(rng.integers(1, 300)), p2=int(rng.integers(1, 300)), slots=int(rng.choice([128, 512, 2048])))
+    elif tuning == "tiny-chunks":
+        t = dict(writers=int(rng.integers(1, 5)), p1=1 << min(la, 6), p2=1 << min(lb, 6), slots=2048, chunk1=16, chunk2=16,
+                 chain1_max=int(rng.integers(4, 40)), chain2_max=int(rng.integers(4, 40)), ovf_capacity=1 << 20)
+    elif tuning == "wide":
+        t = dict(mode=2, p1=1 << min(la, 8), p2=1 << min(lb, 8))
+    try:
+        with pkg.KmerCounter(k, max_kmers_buffered=(1 << 22) * scale, tuning=t) as kc:
+            nb = int(rng.integers(1, 4))  # submit in several pieces
+            cuts = sorted(set([0, nreads] + [int(x) for x in rng.integers(0, nreads + 1, size=nb - 1)]))
+            for a0, a1 in zip(cuts[:-1], cuts[1:]):
+                bb, qq, oo = O.reads_to_arrays(reads[a0:a1], quals[a0:a1])
+                if a1 > a0:
+                    kc.submit_reads(bb, qq, oo)
+            got = kc.sorted_results()
+        ok = all(g.shape == w.shape and (g == w).all() for g, w in zip(got, want))
+    except Exception as e:  # noqa
+        ok = False
+        print("  exception:", repr(e))
+    if not ok:
+        bad += 1
+    print("case %d k=%d reads=%d genome=%d tuning=%s %s -> %s (%d k-mers)" % (c, k, nreads, genome, tuning, t, "ok" if ok else "MISMATCH", len(want[1])), flush=True)
+print("mismatches:", bad)
+sys.exit(1 if bad else 0)

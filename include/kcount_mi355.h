@@ -33,7 +33,8 @@ enum {
   KC_ERR_NO_DEVICE = -3,     /* HIP runtime reports no usable gfx950 device */
   KC_ERR_HIP = -4,           /* a HIP call failed; kc_last_error() has the text */
   KC_ERR_OUT_OF_MEMORY = -5,
-  KC_ERR_CAPACITY = -6,      /* caller-provided output buffer too small; nothing was changed, retry with more room */
+  KC_ERR_CAPACITY = -6,      /* a buffer is too small: a caller-provided segment (retry with more room), or the k-mer buffer /
+                                its overflow lists (raise max_kmers_buffered); kc_last_error says which */
   KC_ERR_BAD_BASE = -7,      /* a read holds a byte outside ACGTN/acgtn (reference: DIE at kcount_cpu.cpp:484-486) */
   KC_ERR_STATE = -8          /* call not allowed in this state (e.g. submit after finalize without reset) */
 };

@@ -18,7 +18,7 @@ class KcError(RuntimeError):
         L = lib()
         msg = L.kc_error_string(status).decode()
         detail = L.kc_last_error().decode()
-        super().__init__("%s: %s (%d)%s" % (where, msg, status, (" -- " + detail) if detail and status in (-4, -5, -3) else ""))
+        super().__init__("%s: %s (%d)%s" % (where, msg, status, (" -- " + detail) if detail and status in (-3, -4, -5, -6) else ""))
 
 
 class kc_config(C.Structure):

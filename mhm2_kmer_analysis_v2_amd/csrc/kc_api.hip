@@ -233,7 +233,7 @@ extern "C" const char *kc_error_string(int s) {
     case KC_ERR_NO_DEVICE: return "no usable HIP device";
     case KC_ERR_HIP: return "HIP call failed";
     case KC_ERR_OUT_OF_MEMORY: return "out of device memory";
-    case KC_ERR_CAPACITY: return "output buffer too small";
+    case KC_ERR_CAPACITY: return "a buffer is too small (kc_last_error says which)";
     case KC_ERR_BAD_BASE: return "read holds a byte outside ACGTN";
     case KC_ERR_STATE: return "call not allowed in this state";
     default: return "unknown status";
@@ -952,7 +952,10 @@ extern "C" int kc_extract_partition(kc_ctx *c, const uint8_t *bases, const uint8
   if (rc) return rc;
   for (int d = 0; d < c->cfg.rank_n; d++) h_counts[d] = c->h_ctrs[CTR_BIN0 + d];
   if (c->h_ctrs[CTR_BAD_BASE]) return KC_ERR_BAD_BASE;
-  if (c->h_ctrs[CTR_OVERFLOW]) return KC_ERR_CAPACITY;
+  if (c->h_ctrs[CTR_OVERFLOW]) {
+    snprintf(g_last_error, sizeof(g_last_error), "a shard segment is too small: raise seg_capacity (%llu records)", (unsigned long long)seg_capacity);
+    return KC_ERR_CAPACITY;
+  }
   return KC_OK;
 }
 
@@ -975,7 +978,10 @@ extern "C" int kc_extract_partition_seq_block(kc_ctx *c, const char *seqs, uint6
   if (rc) return rc;
   for (int t = 0; t < c->cfg.rank_n; t++) h_counts[t] = c->h_ctrs[CTR_BIN0 + t];
   if (c->h_ctrs[CTR_BAD_BASE]) return KC_ERR_BAD_BASE;
-  if (c->h_ctrs[CTR_OVERFLOW]) return KC_ERR_CAPACITY;
+  if (c->h_ctrs[CTR_OVERFLOW]) {
+    snprintf(g_last_error, sizeof(g_last_error), "a shard segment is too small: raise seg_capacity (%llu records)", (unsigned long long)seg_capacity);
+    return KC_ERR_CAPACITY;
+  }
   return KC_OK;
 }
 
@@ -1520,7 +1526,10 @@ extern "C" int kc_set_tuning(kc_ctx *c, const kc_tuning *t) {
 template <int NL>
 static int lookup_t(kc_ctx *c, const uint64_t *dq, uint64_t nq, uint16_t *dc, uint8_t *dl, uint8_t *dr) {
   if (!c->d_index) {
-    if (c->out_n >= 0xFFFFFFFFull) return KC_ERR_CAPACITY;
+    if (c->out_n >= 0xFFFFFFFFull) {
+      snprintf(g_last_error, sizeof(g_last_error), "the lookup index holds at most 2^32 - 1 results");
+      return KC_ERR_CAPACITY;
+    }
     uint64_t cap = next_pow2(std::max<uint64_t>(1024, c->out_n * 2));
     HIPCHK(hipMalloc((void **)&c->d_index, cap * 4));
     c->index_cap = cap;

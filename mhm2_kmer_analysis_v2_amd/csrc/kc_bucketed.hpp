@@ -6,16 +6,20 @@
 //
 //   level 1  kc_l1_reads_kernel / kc_l1_records_kernel
 //            reads (or records received from other shards) -> canonical k-mer records, multisplit in LDS
-//            by the low hash bits into P1 buckets; every persistent workgroup appends its runs to
-//            segments it alone owns (writer g, bucket b), so no global atomics and no ordering hazards.
+//            into P1 buckets; every persistent workgroup appends its runs to segments it alone owns
+//            (writer g, bucket b), so no global atomics and no ordering hazards.
 //   level 2  kc_l2_split_kernel
-//            one workgroup per bucket streams the bucket's G segments, multisplits by the next hash bits
-//            into P2 regions and appends to region arrays it alone owns.
+//            one workgroup per bucket streams the bucket's G segments, multisplits into P2 regions and
+//            appends to region arrays it alone owns.
 //   count    kc_count_kernel
 //            one workgroup per region: an open-addressed (linear probe) table of S slots lives in LDS
 //            -- the "probe window" of the region; records are streamed once, keys claimed by LDS
 //            compare-and-swap, count / extension votes bumped by LDS atomics; then S7 vote, S8 purge
 //            and a ballot/prefix compaction straight into the dense result arrays.
+//
+// Bucket, region and probe start are fields of the k-mer's 64-bit hash (hash_b1, hash_b2, hash_slot) -- or, for
+// short one-word k-mers, bits of an invertible mix of the k-mer itself (Geom::cp, "compact records"): the region
+// then implies part of the k-mer, level 2 stores the rest in 32 bits, and nobody hashes a record again.
 //
 // A region that does not fit (too many records for its array, or more distinct k-mers than LDS slots)
 // is flagged and handled, whole, by the global-table kernels of kc_kernels.hpp, so every k-mer lives in

@@ -26,6 +26,15 @@ def test_adapters_compile_and_link(tmp_path):
     assert os.path.exists(build(tmp_path))
 
 
+def test_compact_record_mix_is_a_bijection(tmp_path):
+    """kc_feistel_fwd / kc_feistel_inv (host build of kc_common.hpp): a permutation with the stated inverse, evenly
+    spread bucket / region / slot bits (tests/cpp/test_mix.cpp)."""
+    exe = os.path.join(str(tmp_path), "test_mix")
+    subprocess.check_call(["g++", "-O2", "-std=c++17", "-o", exe, os.path.join(ROOT, "tests", "cpp", "test_mix.cpp")])
+    out = subprocess.run([exe], capture_output=True, text=True)
+    assert out.returncode == 0 and out.stdout.strip() == "bad=0", out.stdout
+
+
 @pytest.mark.gpu
 @pytest.mark.parametrize("mode", ["records", "ascii", "packed"])
 def test_cpp_driver_matches_oracle(tmp_path, mode):

@@ -557,10 +557,12 @@ static int set_dyn_lds(K kernel, size_t bytes) {
   return KC_OK;
 }
 
-// the sorted staging plus one uint16 bucket id per staged record
+// dynamic LDS of the split kernels: the working set, the sorted staging and (level 1 from reads, wide records) one
+// uint16 bucket id per staged record; the sender-side binning stages nothing
 template <int NL> static size_t lds_l1_reads() {
-  return ((sizeof(L1LDS) + 15) & ~size_t(15)) + Rnd<NL>::STAGE_READS + (size_t)WGB * Rnd<NL>::RPOS_READS * 2;
+  return ((sizeof(L1LDS) + 15) & ~size_t(15)) + Rnd<NL>::STAGE_READS + ((size_t)WGB * Rnd<NL>::RPOS_READS + 64) * 2;
 }
+template <int NL> static size_t lds_bin_reads() { return (sizeof(L1LDS) + 15) & ~size_t(15); }
 template <int NL> static size_t lds_l1_records() { return ((sizeof(L1RLDS) + 15) & ~size_t(15)) + Rnd<NL>::STAGE; }
 template <int NL> static size_t lds_l2() { return ((sizeof(L2LDS) + 15) & ~size_t(15)) + Rnd<NL>::STAGE; }
 
@@ -569,7 +571,9 @@ template <int NL> static bool use_cp(const kc_ctx *c) { return NL == 1 && c->gm.
 
 template <int NL, int FMT>
 static int launch_l1_reads_t(kc_ctx *c, const ExtractArgs &a, uint64_t nsuper) {
-  auto kern = use_cp<NL>(c) ? kc_l1_reads_kernel<NL, FMT, NL == 1> : kc_l1_reads_kernel<NL, FMT, false>;
+  const bool sh = c->cfg.rank_n > 1;
+  auto kern = use_cp<NL>(c) ? (sh ? kc_l1_reads_kernel<NL, FMT, NL == 1, true> : kc_l1_reads_kernel<NL, FMT, NL == 1, false>)
+                            : (sh ? kc_l1_reads_kernel<NL, FMT, false, true> : kc_l1_reads_kernel<NL, FMT, false, false>);
   int rc = set_dyn_lds(kern, lds_l1_reads<NL>());
   if (rc) return rc;
   const unsigned grid = (unsigned)std::min<uint64_t>(c->gm.G, nsuper);
@@ -615,11 +619,11 @@ static int launch_l1_reads(kc_ctx *c, const ExtractArgs &a, uint64_t ntiles, int
 template <int NL, int FMT>
 static int launch_bin_reads_t(kc_ctx *c, const ExtractArgs &a, uint64_t nsuper) {
   auto kern = kc_bin_reads_kernel<NL, FMT>;
-  int rc = set_dyn_lds(kern, lds_l1_reads<NL>());
+  int rc = set_dyn_lds(kern, lds_bin_reads<NL>());
   if (rc) return rc;
   const unsigned grid = (unsigned)std::min<uint64_t>((uint64_t)c->num_cus, nsuper);
   KernelTimer kt(c, KT_EXTRACT_BIN);
-  hipLaunchKernelGGL(kern, dim3(grid), dim3(WGB), lds_l1_reads<NL>(), c->stream, a, nsuper, c->d_ctrs);
+  hipLaunchKernelGGL(kern, dim3(grid), dim3(WGB), lds_bin_reads<NL>(), c->stream, a, nsuper, c->d_ctrs);
   return KC_OK;
 }
 

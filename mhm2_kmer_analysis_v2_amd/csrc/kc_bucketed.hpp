@@ -41,13 +41,15 @@ static_assert(TileSuper::GPT == 1 && TileSuper::NGROUP == WGB, "one group per th
 constexpr int PMAX = 1024;       // max fan-out of either level
 constexpr int GMAX = 512;        // max level-1 writers
 
-// RPOS: when the records come from memory; RPOS_READS: when each is cut out of a staged tile (more live registers)
+// records a thread holds per round: RPOS when they come from memory, RPOS_READS when each is cut out of a staged tile
+// (more live registers)
 template <int NL> struct Rnd {
   static constexpr int RPOS = NL == 1 ? 16 : NL == 2 ? 8 : 4;
   static constexpr int RPOS_READS = NL == 1 ? 8 : NL <= 3 ? 4 : 2;
-  // sorted staging of one round: <= 128 KiB from memory, <= 96 KiB from tiles (the tiles need LDS too)
-  static constexpr size_t STAGE = (size_t)WGB * RPOS * NL * 8;
-  static constexpr size_t STAGE_READS = (size_t)WGB * RPOS_READS * NL * 8;
+  // sorted staging of one round (+ one slot per lane of a wave for the positions that hold no record):
+  // <= 128 KiB from memory, <= 96 KiB from tiles (the tiles need LDS too)
+  static constexpr size_t STAGE = ((size_t)WGB * RPOS + 64) * NL * 8;
+  static constexpr size_t STAGE_READS = ((size_t)WGB * RPOS_READS + 64) * NL * 8;
 };
 
 // Destination arrays are chains of fixed-size chunks taken from an arena that only its owner allocates
@@ -129,7 +131,7 @@ __device__ __forceinline__ uint64_t rec_hash(const uint64_t (&rec)[NL]) {
 }
 
 // Barrier for data exchanged through LDS only.  __syncthreads() also drains the vector-memory counter,
-// which would serialise the global loads these kernels keep in flight across their LDS phases.
+// which would serialise the global loads and stores these kernels keep in flight across their LDS phases.
 __device__ __forceinline__ void lds_barrier() { asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory"); }
 
 // ---- workgroup exclusive scan over WGB values --------------------------------------------------
@@ -164,17 +166,23 @@ __device__ __forceinline__ uint32_t block_excl_scan(uint32_t v, ScanLDS &S) {
 }
 
 // ---- multisplit of one round of records held in registers ---------------------------------------
-// LDS working set shared by both split kernels
+// A round: every thread ranks its records inside their destinations with LDS atomics on a histogram (br[] = bucket |
+// rank << 10); the histogram is scanned, the thread that owns a destination (thread b owns destination b) reserves room
+// for the round's run at the end of that destination's chain; the records are scattered into an LDS staging sorted by
+// destination and copied out run by run, so that HBM sees stores of consecutive records.  (Storing the records from
+// the registers straight to their scattered places was tried: every lane's store is then a memory request of its own,
+// and both split kernels took 1.3-1.8x as long.)
+// No LDS read sits inside a branch in the scatter and the copy-out: a read inside a conditional block is waited for at
+// the end of that block, which would put the reads of a thread's records one behind the other.
 struct SplitLDS {
   uint32_t hist[2][PMAX];  // per-bucket counts of this round (double-buffered)
-  // what the copy-out needs to know about a bucket's run, in one 64-bit read: bits 0-15 where the run starts in the
-  // sorted staging (exclusive prefix), 16-31 how many of its records found room, 32-47 how many of those still go
-  // into the chain's old last chunk
-  uint64_t meta[PMAX];
-  // record index (relative to the owner's part of the arena) of the run's element 0 as seen from the old last chunk
-  // [0] and from the round's new chunks [1]: the new chunks of a round are consecutive, so inside either the index
-  // is linear in the element's rank
-  uint32_t ab[2][PMAX];
+  // what scatter and copy-out need to know about a destination's run, in one 16-byte read.  i = an element's index in
+  // the sorted staging, s = where the run starts there (exclusive prefix):
+  //   x, y = record index (relative to the owner's part of the arena) of element i, minus i, as seen from the chain's
+  //          old last chunk and from the round's new chunks (the new chunks of a round are consecutive, so inside
+  //          either the index is linear in i);  z = s | how many of the run's records found room << 16;
+  //   w = how many of those still go into the old last chunk
+  uint4 dst[PMAX];
   uint32_t arena_used;     // chunks taken from the owner's arena
   ScanLDS scan;
 };
@@ -209,16 +217,16 @@ struct ChainState {
   uint32_t last;  // id of its last chunk (valid when cur is not chunk-aligned)
 };
 
-// Phase 2-4 of a round: scan, reserve, scatter to LDS, copy out.  The caller has already bumped
-// hist[buf] with LDS atomics (bucket | rank<<10 in br[], ~0 for "no record") and hit a barrier.
-//   bucket_of(rec) recomputes a record's bucket during copy-out; overflow(b, rec) takes what found no room;
+// Scan, reserve, scatter to LDS, copy out.  The caller has already bumped hist[buf] with LDS atomics (bucket |
+// rank<<10 in br[], ~0 for "no record") and hit a barrier.
+//   bucket_of(rec) gives a staged record's bucket during copy-out where that is cheap (sbucket == nullptr); otherwise
+//   sbucket, an LDS array parallel to `sorted`, remembers it; overflow(b, rec) takes what found no room;
 //   store(i, rec) writes a record to position i (in records) of the destination arena
 template <int NL, int R, class BucketFn, class OvfFn, class StoreFn>
 __device__ __forceinline__ void split_round(SplitLDS &L, uint64_t *sorted, uint16_t *sbucket, int buf, uint32_t P,
                                             const uint64_t (&rec)[R][NL], const uint32_t (&br)[R], const ChainDest &D, ChainState &st,
                                             BucketFn bucket_of, OvfFn overflow, StoreFn store) {
-  // sbucket: optional LDS array parallel to `sorted` that remembers each staged record's bucket, so that the copy-out
-  // need not hash the record again (null where the LDS has no room for it)
+  static_assert(R * WGB <= 32768, "positions in the staging must fit 16 bits");
   const int tid = threadIdx.x;
   KC_SPLIT_STAMP(1)  // barrier after the histogram
   const uint32_t v = ((uint32_t)tid < P) ? L.hist[buf][tid] : 0u;
@@ -243,10 +251,12 @@ __device__ __forceinline__ void split_round(SplitLDS &L, uint64_t *sorted, uint1
     }
     // element j of the run sits at chain position base + j: in the old last chunk (id st.last) while that has room,
     // then in the new chunks a, a+1, ... whose first one holds chain positions have << log2CH onwards
-    const uint32_t in_old = (base & CHm) ? min(fit, (CHm + 1u) - (base & CHm)) : 0u;
-    L.ab[0][tid] = ((st.last - D.arena_base - (base >> D.log2CH)) << D.log2CH) + base;
-    L.ab[1][tid] = ((a - have) << D.log2CH) + base;
-    L.meta[tid] = (uint64_t)excl | ((uint64_t)fit << 16) | ((uint64_t)in_old << 32);
+    uint4 d;
+    d.x = ((st.last - D.arena_base - (base >> D.log2CH)) << D.log2CH) + base - excl;
+    d.y = ((a - have) << D.log2CH) + base - excl;
+    d.z = excl | (fit << 16);
+    d.w = (base & CHm) ? min(fit, (CHm + 1u) - (base & CHm)) : 0u;
+    L.dst[tid] = d;
     if (k) st.last = D.arena_base + a + k - 1;
     st.cur = base + fit;
     L.hist[buf ^ 1][tid] = 0;  // next round's histogram
@@ -254,53 +264,59 @@ __device__ __forceinline__ void split_round(SplitLDS &L, uint64_t *sorted, uint1
   lds_barrier();
   KC_SPLIT_STAMP(2)  // scan + reserve
   const uint32_t total = L.scan.total;
+  {
+    // all the run starts first, then all the writes; a position without a record goes to a slot of its lane's behind
+    // the staging
+    uint32_t pos[R];
 #pragma unroll
-  for (int j = 0; j < R; j++) {
-    if (br[j] != ~0u) {
-      const uint32_t b = br[j] & (PMAX - 1), rank = br[j] >> 10;
-      const uint32_t pos = ((uint32_t)L.meta[b] & 0xFFFFu) + rank;
+    for (int j = 0; j < R; j++) pos[j] = L.dst[br[j] & (PMAX - 1)].z;
 #pragma unroll
-      for (int w = 0; w < NL; w++) sorted[(size_t)pos * NL + w] = rec[j][w];
-      if (sbucket) sbucket[pos] = (uint16_t)b;
+    for (int j = 0; j < R; j++) {
+      const uint32_t p = br[j] != ~0u ? (pos[j] & 0xFFFFu) + (br[j] >> 10) : (uint32_t)(R * WGB) + lane_id();
+#pragma unroll
+      for (int w = 0; w < NL; w++) sorted[(size_t)p * NL + w] = rec[j][w];
+      if (sbucket) sbucket[p] = (uint16_t)(br[j] & (PMAX - 1));
     }
   }
   lds_barrier();
   KC_SPLIT_STAMP(3)  // scatter to LDS
-  // copy out, U elements per thread and trip: the LDS reads and the bucket look-ups of the U elements are
-  // independent chains the hardware can overlap (one element per trip is a single long dependent chain per wave)
+  // copy out, U elements per thread and trip: first all their records, then all their destinations, then the stores
   constexpr int U = NL == 1 ? 4 : 2;
   const size_t arena0 = (size_t)D.arena_base << D.log2CH;
   for (uint32_t i0 = tid; i0 < total; i0 += U * WGB) {
     uint64_t r[U][NL];
     uint32_t b[U];
+    uint4 d[U];
 #pragma unroll
     for (int u = 0; u < U; u++) {
       const uint32_t i = i0 + u * WGB;
       const uint32_t ii = i < total ? i : i0;  // in range: i0 < total
 #pragma unroll
       for (int w = 0; w < NL; w++) r[u][w] = sorted[(size_t)ii * NL + w];
+      if (sbucket) b[u] = sbucket[ii];
     }
-    if (sbucket) {
-#pragma unroll
-      for (int u = 0; u < U; u++) {
-        const uint32_t i = i0 + u * WGB;
-        b[u] = sbucket[i < total ? i : i0];
-      }
-    } else {
+    if (!sbucket) {
 #pragma unroll
       for (int u = 0; u < U; u++) b[u] = bucket_of(r[u]);
     }
 #pragma unroll
+    for (int u = 0; u < U; u++) d[u] = L.dst[b[u]];
+    bool spill = false;
+#pragma unroll
     for (int u = 0; u < U; u++) {
       const uint32_t i = i0 + u * WGB;
-      if (i >= total) break;
-      const uint64_t m = L.meta[b[u]];
-      const uint32_t j = i - ((uint32_t)m & 0xFFFFu);
-      if (j < (((uint32_t)m >> 16) & 0xFFFFu)) {
-        const uint32_t at = L.ab[j >= (uint32_t)(m >> 32) ? 1 : 0][b[u]] + j;
-        store(arena0 + at, r[u]);
-      } else {
-        overflow(b[u], r[u]);
+      const uint32_t j = i - (d[u].z & 0xFFFFu);
+      const bool live = i < total, fits = j < (d[u].z >> 16);
+      // x and y are "index minus staging position" modulo 2^32: the sum must wrap in 32 bits before it is widened
+      const uint32_t at = (j < d[u].w ? d[u].x : d[u].y) + i;
+      if (live && fits) store(arena0 + at, r[u]);
+      spill |= live && !fits;
+    }
+    if (__any(spill)) {  // rare: a chain or the arena is full
+#pragma unroll
+      for (int u = 0; u < U; u++) {
+        const uint32_t i = i0 + u * WGB;
+        if (i < total && i - (d[u].z & 0xFFFFu) >= (d[u].z >> 16)) overflow(b[u], r[u]);
       }
     }
   }
@@ -318,7 +334,7 @@ __device__ __forceinline__ void store_words(uint64_t *arena, size_t i, const uin
 
 // load the persistent state of this owner's P chains (before its first round)
 __device__ __forceinline__ ChainState split_load_state(SplitLDS &L, uint32_t P, const uint32_t *cnt, const uint32_t *chain,
-                                                       uint32_t LMAX, uint32_t log2CH, uint32_t chain_id_base, uint32_t used) {
+                                                       uint32_t LMAX, uint32_t log2CH, uint32_t used) {
   const int tid = threadIdx.x;
   ChainState st;
   st.cur = 0;
@@ -331,7 +347,6 @@ __device__ __forceinline__ ChainState split_load_state(SplitLDS &L, uint32_t P, 
     L.hist[1][tid] = 0;
   }
   if (tid == 0) L.arena_used = used;
-  (void)chain_id_base;
   return st;
 }
 
@@ -339,6 +354,7 @@ __device__ __forceinline__ ChainState split_load_state(SplitLDS &L, uint32_t P, 
 struct L1LDS {
   TileLDS<TileSuper> tile;
   SplitLDS sp;
+  uint32_t idle[64];  // what the positions without a k-mer add to (one word per lane: no two lanes share one)
 };
 
 template <int NL>
@@ -369,13 +385,16 @@ __device__ __forceinline__ void l1_overflow(const Geom &gm, const BucketBufs &bb
   }
 }
 
-template <int NL, int FMT, bool CP>
+// SH: the context is one shard of several and keeps only the k-mers it owns (kc_submit_reads with rank_n > 1); the
+// single-shard instantiation carries none of the ownership code.
+template <int NL, int FMT, bool CP, bool SH>
 __global__ __launch_bounds__(WGB) void kc_l1_reads_kernel(ExtractArgs a, Geom gm, BucketBufs bb, uint64_t nsuper, uint32_t rot,
                                                           uint64_t *ctrs, uint64_t *cb) {
   extern __shared__ __align__(16) uint8_t smem[];
   L1LDS &L = *reinterpret_cast<L1LDS *>(smem);
   uint64_t *sorted = reinterpret_cast<uint64_t *>(smem + ((sizeof(L1LDS) + 15) & ~size_t(15)));
-  uint16_t *sbucket = reinterpret_cast<uint16_t *>(smem + ((sizeof(L1LDS) + 15) & ~size_t(15)) + Rnd<NL>::STAGE_READS);
+  // wide records: the bucket of a staged record is remembered beside it (compact ones carry it in their top bits)
+  uint16_t *sbucket = CP ? nullptr : reinterpret_cast<uint16_t *>(smem + ((sizeof(L1LDS) + 15) & ~size_t(15)) + Rnd<NL>::STAGE_READS);
   constexpr int RPOS = Rnd<NL>::RPOS_READS;
   const int tid = threadIdx.x;
   // writer id: launches rotate their first writer (rot) so that many small submits still spread evenly
@@ -386,7 +405,8 @@ __global__ __launch_bounds__(WGB) void kc_l1_reads_kernel(ExtractArgs a, Geom gm
   D.stamps = cb + 8;
   D.tprev = &tprev_;
 #endif
-  ChainState cst = split_load_state(L.sp, P1, bb.cnt1 + (size_t)g * P1, D.chain, D.LMAX, D.log2CH, 0, bb.used1[g]);
+  ChainState cst = split_load_state(L.sp, P1, bb.cnt1 + (size_t)g * P1, D.chain, D.LMAX, D.log2CH, bb.used1[g]);
+  if (tid < 64) L.idle[tid] = 0;
   __syncthreads();
   uint32_t n_ins = 0;
   int buf = 0;
@@ -421,30 +441,34 @@ __global__ __launch_bounds__(WGB) void kc_l1_reads_kernel(ExtractArgs a, Geom gm
       for (int j = 0; j < RPOS; j++) {
         uint64_t h = 0;
         uint32_t owner = 0;
-        bool valid = run_kmer<NL, !CP>(run, j, lp0, a.k, rec[j], h, a.rank_n, a.reference_owner, &owner) && active;
-        if (CP && a.rank_n > 1 && !a.reference_owner) {
-          uint64_t key[NL];
+        bool valid = run_kmer<NL, !CP>(run, j, lp0, a.k, rec[j], h, SH ? a.rank_n : 1u, SH ? a.reference_owner : 0u, SH ? &owner : nullptr) && active;
+        if (SH) {
+          if (CP && !a.reference_owner) {
+            uint64_t key[NL];
 #pragma unroll
-          for (int w = 0; w < NL; w++) key[w] = rec[j][w];
-          key[NL - 1] &= ~KC_EXT_MASK;
-          owner = kc_owner_of_hash(kc_hash<NL>(key), a.rank_n);
+            for (int w = 0; w < NL; w++) key[w] = rec[j][w];
+            key[NL - 1] &= ~KC_EXT_MASK;
+            owner = kc_owner_of_hash(kc_hash<NL>(key), a.rank_n);
+          }
+          valid = valid && owner == a.rank_me;
         }
-        if (a.rank_n > 1) valid = valid && owner == a.rank_me;
         if (CP) rec[j][0] = cp_mix_rec(rec[j][0], gm);
-        br[j] = ~0u;
-        if (valid) {
-          const uint32_t b = CP ? cp_b1(rec[j][0], gm) : hash_b1(h, gm);
-          const uint32_t rank = atomicAdd(&L.sp.hist[buf][b], 1u);
-          br[j] = b | (rank << 10);
-          n_ins++;
-        }
+        br[j] = valid ? (CP ? cp_b1(rec[j][0], gm) : hash_b1(h, gm)) : ~0u;
         if (j + 1 < RPOS) run_advance<NL>(run, j, lp0, a.k);
+      }
+      // the ranks: one LDS add per record, all of a thread's adds in flight together (no branch around them: a
+      // position without a k-mer bumps a word of its own lane's instead)
+#pragma unroll
+      for (int j = 0; j < RPOS; j++) {
+        const bool valid = br[j] != ~0u;
+        const uint32_t rank = atomicAdd(valid ? &L.sp.hist[buf][br[j]] : &L.idle[lane_id()], 1u);
+        br[j] = valid ? (br[j] | (rank << 10)) : ~0u;
+        n_ins += valid ? 1u : 0u;
       }
       KC_SPLIT_STAMP(0)  // cut the k-mers out of the super-tile, histogram
       lds_barrier();
       split_round<NL, RPOS>(
-          L.sp, sorted, sbucket, buf, P1, rec, br, D, cst,
-          [&](const uint64_t (&r)[NL]) { return CP ? cp_b1(r[0], gm) : hash_b1(rec_hash<NL>(r), gm); },
+          L.sp, sorted, sbucket, buf, P1, rec, br, D, cst, [&](const uint64_t (&r)[NL]) { return cp_b1(r[0], gm); },
           [&](uint32_t, const uint64_t (&r)[NL]) { l1_overflow<NL, CP>(gm, bb, cb, r); },
           [&](size_t i, const uint64_t (&r)[NL]) { store_words<NL>(D.arena, i, r); });
       buf ^= 1;
@@ -457,53 +481,39 @@ __global__ __launch_bounds__(WGB) void kc_l1_reads_kernel(ExtractArgs a, Geom gm
 }
 
 // ---- sender side of the shard exchange: bin a block's records by owner shard ------------------------------
-// Same tile extraction and LDS multisplit as level 1, with the owner shard as the bucket and the caller's
-// per-shard segments as destinations: one global cursor bump per shard and round (a handful of atomics per
-// 8 Ki records) instead of one per wave and shard.
+// Same tile extraction and ranking as level 1, with the owner shard as the bucket and the caller's per-shard segments
+// as destinations: one global cursor bump per shard and round (a handful of atomics per 8 Ki records) instead of one
+// per wave and shard, and the records go from the registers straight to their segment.
 template <int NL, int R>
-__device__ __forceinline__ void split_round_flat(SplitLDS &L, uint64_t *sorted, uint16_t *sbucket, int buf, uint32_t P,
-                                                 const uint64_t (&rec)[R][NL], const uint32_t (&br)[R], uint64_t *records, uint64_t seg_cap,
-                                                 uint64_t *cursors, uint64_t *overflow_flag) {
+__device__ __forceinline__ void split_round_flat(SplitLDS &L, int buf, uint32_t P, const uint64_t (&rec)[R][NL], const uint32_t (&br)[R],
+                                                 uint64_t *records, uint64_t seg_cap, uint64_t *cursors, uint64_t *overflow_flag) {
   const int tid = threadIdx.x;
-  uint32_t *H = L.hist[buf];
-  const uint32_t v = ((uint32_t)tid < P) ? H[tid] : 0u;
-  const uint32_t excl = block_excl_scan(v, L.scan);
   if ((uint32_t)tid < P) {
-    L.meta[tid] = excl;
+    const uint32_t v = L.hist[buf][tid];
     uint64_t base = 0;
     if (v) base = atomicAdd((unsigned long long *)&cursors[tid], (unsigned long long)v);
     const uint64_t room = base < seg_cap ? seg_cap - base : 0;
-    L.ab[0][tid] = (uint32_t)base;
-    L.ab[1][tid] = (uint32_t)(base >> 32);
-    H[tid] = (uint64_t)v <= room ? v : (uint32_t)room;
+    uint4 d;
+    d.x = (uint32_t)base;
+    d.y = (uint32_t)(base >> 32);
+    d.z = (uint64_t)v <= room ? v : (uint32_t)room;
+    d.w = 0;
+    L.dst[tid] = d;
     L.hist[buf ^ 1][tid] = 0;
   }
   lds_barrier();
-  const uint32_t total = L.scan.total;
 #pragma unroll
   for (int j = 0; j < R; j++) {
     if (br[j] != ~0u) {
       const uint32_t b = br[j] & (PMAX - 1), rank = br[j] >> 10;
-      const uint32_t pos = (uint32_t)L.meta[b] + rank;
+      const uint4 d = L.dst[b];
+      if (rank < d.z) {
+        uint64_t *o = records + ((uint64_t)b * seg_cap + (((uint64_t)d.y << 32) | d.x) + rank) * NL;
 #pragma unroll
-      for (int w = 0; w < NL; w++) sorted[(size_t)pos * NL + w] = rec[j][w];
-      sbucket[pos] = (uint16_t)b;  // the owner shard travels with the staged record: no second hash at copy-out
-    }
-  }
-  lds_barrier();
-  for (uint32_t i = tid; i < total; i += WGB) {
-    uint64_t r[NL];
-#pragma unroll
-    for (int w = 0; w < NL; w++) r[w] = sorted[(size_t)i * NL + w];
-    const uint32_t b = sbucket[i];
-    const uint32_t j = i - (uint32_t)L.meta[b];
-    if (j < H[b]) {
-      const uint64_t base = ((uint64_t)L.ab[1][b] << 32) | L.ab[0][b];
-      uint64_t *d = records + ((uint64_t)b * seg_cap + base + j) * NL;
-#pragma unroll
-      for (int w = 0; w < NL; w++) d[w] = r[w];
-    } else {
-      *overflow_flag = 1;
+        for (int w = 0; w < NL; w++) o[w] = rec[j][w];
+      } else {
+        *overflow_flag = 1;
+      }
     }
   }
 }
@@ -512,8 +522,6 @@ template <int NL, int FMT>
 __global__ __launch_bounds__(WGB) void kc_bin_reads_kernel(ExtractArgs a, uint64_t nsuper, uint64_t *ctrs) {
   extern __shared__ __align__(16) uint8_t smem[];
   L1LDS &L = *reinterpret_cast<L1LDS *>(smem);
-  uint64_t *sorted = reinterpret_cast<uint64_t *>(smem + ((sizeof(L1LDS) + 15) & ~size_t(15)));
-  uint16_t *sbucket = reinterpret_cast<uint16_t *>(smem + ((sizeof(L1LDS) + 15) & ~size_t(15)) + Rnd<NL>::STAGE_READS);
   constexpr int RPOS = Rnd<NL>::RPOS_READS;
   const int tid = threadIdx.x;
   const uint32_t P = a.rank_n;
@@ -574,7 +582,7 @@ __global__ __launch_bounds__(WGB) void kc_bin_reads_kernel(ExtractArgs a, uint64
         }
       }
       lds_barrier();
-      split_round_flat<NL, RPOS>(L.sp, sorted, sbucket, buf, P, rec, br, a.records, a.seg_capacity, ctrs + CTR_BIN0, ctrs + CTR_OVERFLOW);
+      split_round_flat<NL, RPOS>(L.sp, buf, P, rec, br, a.records, a.seg_capacity, ctrs + CTR_BIN0, ctrs + CTR_OVERFLOW);
       buf ^= 1;
     }
   }
@@ -595,7 +603,7 @@ __global__ __launch_bounds__(WGB) void kc_l1_records_kernel(const uint64_t *recs
   const int tid = threadIdx.x;
   const uint32_t g = (blockIdx.x + rot) % gm.G, P1 = gm.P1;
   const ChainDest D = l1_dest<NL>(gm, bb, g);
-  ChainState cst = split_load_state(L.sp, P1, bb.cnt1 + (size_t)g * P1, D.chain, D.LMAX, D.log2CH, 0, bb.used1[g]);
+  ChainState cst = split_load_state(L.sp, P1, bb.cnt1 + (size_t)g * P1, D.chain, D.LMAX, D.log2CH, bb.used1[g]);
   __syncthreads();
   const uint64_t per_round = (uint64_t)WGB * RPOS;
   const uint64_t nrounds = (n + per_round - 1) / per_round;
@@ -724,7 +732,7 @@ __global__ __launch_bounds__(WGB) void kc_l2_split_kernel(Geom gm, BucketBufs bb
     D.stamps = cb + 8;
     D.tprev = &tprev_;
 #endif
-    ChainState cst = split_load_state(L.sp, P2, nullptr, D.chain, D.LMAX, D.log2CH, D.arena_base, 0);
+    ChainState cst = split_load_state(L.sp, P2, nullptr, D.chain, D.LMAX, D.log2CH, 0);
     __syncthreads();
     const uint32_t n = L.pre[G];
     const uint32_t per_round = WGB * RPOS;

@@ -572,8 +572,13 @@ template <int NL> static bool use_cp(const kc_ctx *c) { return NL == 1 && c->gm.
 template <int NL, int FMT>
 static int launch_l1_reads_t(kc_ctx *c, const ExtractArgs &a, uint64_t nsuper) {
   const bool sh = c->cfg.rank_n > 1;
-  auto kern = use_cp<NL>(c) ? (sh ? kc_l1_reads_kernel<NL, FMT, NL == 1, true> : kc_l1_reads_kernel<NL, FMT, NL == 1, false>)
-                            : (sh ? kc_l1_reads_kernel<NL, FMT, false, true> : kc_l1_reads_kernel<NL, FMT, false, false>);
+  // compact records at k = 21 (MHM2's first and only one-word k of its default sweep, src/options.hpp:80): the
+  // instantiation made for that k; any other k takes the general one
+  constexpr int K21 = NL == 1 ? 21 : 0;
+  const bool k21 = NL == 1 && c->k == 21 && c->gm.k2 - c->gm.la <= 32;  // its registers hold the 32 bits below the bucket
+  auto kern = use_cp<NL>(c) ? (k21 ? (sh ? kc_l1_reads_kernel<NL, FMT, NL == 1, true, K21> : kc_l1_reads_kernel<NL, FMT, NL == 1, false, K21>)
+                                   : (sh ? kc_l1_reads_kernel<NL, FMT, NL == 1, true, 0> : kc_l1_reads_kernel<NL, FMT, NL == 1, false, 0>))
+                            : (sh ? kc_l1_reads_kernel<NL, FMT, false, true, 0> : kc_l1_reads_kernel<NL, FMT, false, false, 0>);
   int rc = set_dyn_lds(kern, lds_l1_reads<NL>());
   if (rc) return rc;
   const unsigned grid = (unsigned)std::min<uint64_t>(c->gm.G, nsuper);
@@ -1128,7 +1133,10 @@ static int table_finalize_append(kc_ctx *c) {
 // ---- bucketed path: regions, counting, flagged regions ------------------------------------------
 template <int NL>
 static int bk_level2_t(kc_ctx *c) {
-  auto kern = use_cp<NL>(c) ? kc_l2_split_kernel<NL, NL == 1> : kc_l2_split_kernel<NL, false>;
+  // short register form: compact records whose mix fits 32 bits below the level-1 bucket
+  const bool cr = use_cp<NL>(c) && c->gm.k2 - c->gm.la <= 32;
+  auto kern = use_cp<NL>(c) ? (cr ? kc_l2_split_kernel<NL, NL == 1, NL == 1> : kc_l2_split_kernel<NL, NL == 1, false>)
+                            : kc_l2_split_kernel<NL, false, false>;
   int rc = set_dyn_lds(kern, lds_l2<NL>());
   if (rc) return rc;
   hipLaunchKernelGGL(kc_bucket_prefix_kernel, dim3(1), dim3(WGB), 0, c->stream, c->gm, c->bb, c->d_cb);

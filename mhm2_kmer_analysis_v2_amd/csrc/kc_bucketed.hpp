@@ -140,12 +140,16 @@ struct ScanLDS {
   uint32_t total;
 };
 
+// Inclusive scan over the 64 lanes of a wave with data-parallel-primitive moves (no LDS traffic, unlike a shuffle,
+// which goes through the LDS crossbar): four shifted adds scan each row of 16 lanes, two broadcasts carry the row totals
+// on.  A lane whose source lies outside its row (or whose row a broadcast does not address) adds the zero given as `old`.
 __device__ __forceinline__ uint32_t wave_incl_scan(uint32_t v) {
-#pragma unroll
-  for (int o = 1; o < 64; o <<= 1) {
-    uint32_t n = __shfl_up(v, o);
-    if ((int)lane_id() >= o) v += n;
-  }
+  v += (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, 0x111, 0xF, 0xF, false);  // row_shr:1
+  v += (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, 0x112, 0xF, 0xF, false);  // row_shr:2
+  v += (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, 0x114, 0xF, 0xF, false);  // row_shr:4
+  v += (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, 0x118, 0xF, 0xF, false);  // row_shr:8
+  v += (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, 0x142, 0xA, 0xF, false);  // row_bcast:15 into rows 1 and 3
+  v += (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, 0x143, 0xC, 0xF, false);  // row_bcast:31 into rows 2 and 3
   return v;
 }
 
@@ -153,14 +157,20 @@ __device__ __forceinline__ uint32_t wave_incl_scan(uint32_t v) {
 // caller's next barrier).  One barrier inside: every wave scans the 16 wave totals itself instead of waiting for
 // wave 0 to do it.
 __device__ __forceinline__ uint32_t block_excl_scan(uint32_t v, ScanLDS &S) {
-  const int tid = threadIdx.x, wave = tid >> 6;
+  static_assert(WGB / 64 <= 16, "the wave totals must fit one row of 16 lanes");
+  const int tid = threadIdx.x;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
   const uint32_t incl = wave_incl_scan(v);
   if (lane_id() == 63) S.wsum[wave] = incl;
   lds_barrier();
   const uint32_t w = (lane_id() < WGB / 64) ? S.wsum[lane_id()] : 0u;
-  const uint32_t wi = wave_incl_scan(w);
-  const uint32_t wave_pre = __shfl(wi - w, wave);             // exclusive prefix of this wave's total
-  const uint32_t total = __shfl(wi, WGB / 64 - 1);            // shuffles outside any branch: every lane takes part
+  uint32_t wi = w;  // the 16 totals sit in row 0: a row scan is enough
+  wi += (uint32_t)__builtin_amdgcn_update_dpp(0, (int)wi, 0x111, 0xF, 0xF, false);
+  wi += (uint32_t)__builtin_amdgcn_update_dpp(0, (int)wi, 0x112, 0xF, 0xF, false);
+  wi += (uint32_t)__builtin_amdgcn_update_dpp(0, (int)wi, 0x114, 0xF, 0xF, false);
+  wi += (uint32_t)__builtin_amdgcn_update_dpp(0, (int)wi, 0x118, 0xF, 0xF, false);
+  const uint32_t wave_pre = (uint32_t)__builtin_amdgcn_readlane((int)(wi - w), wave);  // exclusive prefix of this wave's total
+  const uint32_t total = (uint32_t)__builtin_amdgcn_readlane((int)wi, WGB / 64 - 1);
   if (tid == 0) S.total = total;
   return incl - v + wave_pre;
 }
@@ -217,16 +227,24 @@ struct ChainState {
   uint32_t last;  // id of its last chunk (valid when cur is not chunk-aligned)
 };
 
-// Scan, reserve, scatter to LDS, copy out.  The caller has already bumped hist[buf] with LDS atomics (bucket |
-// rank<<10 in br[], ~0 for "no record") and hit a barrier.
+// A round has two halves.  split_stage: scan, reserve, scatter to LDS; the caller has already bumped hist[buf] with LDS
+// atomics (bucket | rank<<10 in br[], ~0 for "no record") and hit a barrier; returns the number of staged records.
+// split_copy_out: the staged records go to HBM.
+// Between the two a kernel takes delivery of what it prefetched for its next round and sends the next prefetch off:
+// the wait for a load is a wait for every older store of the wave too (one in-order counter, and the compiler, which
+// cannot count the stores of a loop, waits for all of them), so a wait at the top of a round would expose the latency
+// of the copy-out stores just issued; placed here the stores it meets are a whole round old.
 //   bucket_of(rec) gives a staged record's bucket during copy-out where that is cheap (sbucket == nullptr); otherwise
 //   sbucket, an LDS array parallel to `sorted`, remembers it; overflow(b, rec) takes what found no room;
 //   store(i, rec) writes a record to position i (in records) of the destination arena
-template <int NL, int R, class BucketFn, class OvfFn, class StoreFn>
-__device__ __forceinline__ void split_round(SplitLDS &L, uint64_t *sorted, uint16_t *sbucket, int buf, uint32_t P,
-                                            const uint64_t (&rec)[R][NL], const uint32_t (&br)[R], const ChainDest &D, ChainState &st,
-                                            BucketFn bucket_of, OvfFn overflow, StoreFn store) {
+//   rec_of(j, out) hands over record j of the thread: a kernel may keep its records in a shorter form in its registers
+//   (the level-1 record of a compact k-mer is 32 bits + the bucket and extension codes that ride in br[], RS = 16:
+//   br = bucket | extension codes << 10 | rank << 16)
+template <int NL, int R, int RS = 10, class RecFn>
+__device__ __forceinline__ uint32_t split_stage(SplitLDS &L, uint64_t *sorted, uint16_t *sbucket, int buf, uint32_t P, RecFn rec_of,
+                                                const uint32_t (&br)[R], const ChainDest &D, ChainState &st) {
   static_assert(R * WGB <= 32768, "positions in the staging must fit 16 bits");
+  static_assert(RS == 10 || R * WGB <= 65536, "ranks must fit the bits above RS");
   const int tid = threadIdx.x;
   KC_SPLIT_STAMP(1)  // barrier after the histogram
   const uint32_t v = ((uint32_t)tid < P) ? L.hist[buf][tid] : 0u;
@@ -272,14 +290,23 @@ __device__ __forceinline__ void split_round(SplitLDS &L, uint64_t *sorted, uint1
     for (int j = 0; j < R; j++) pos[j] = L.dst[br[j] & (PMAX - 1)].z;
 #pragma unroll
     for (int j = 0; j < R; j++) {
-      const uint32_t p = br[j] != ~0u ? (pos[j] & 0xFFFFu) + (br[j] >> 10) : (uint32_t)(R * WGB) + lane_id();
+      const uint32_t p = br[j] != ~0u ? (pos[j] & 0xFFFFu) + (br[j] >> RS) : (uint32_t)(R * WGB) + lane_id();
+      uint64_t r[NL];
+      rec_of(j, r);
 #pragma unroll
-      for (int w = 0; w < NL; w++) sorted[(size_t)p * NL + w] = rec[j][w];
+      for (int w = 0; w < NL; w++) sorted[(size_t)p * NL + w] = r[w];
       if (sbucket) sbucket[p] = (uint16_t)(br[j] & (PMAX - 1));
     }
   }
   lds_barrier();
   KC_SPLIT_STAMP(3)  // scatter to LDS
+  return total;
+}
+
+template <int NL, class BucketFn, class OvfFn, class StoreFn>
+__device__ __forceinline__ void split_copy_out(SplitLDS &L, const uint64_t *sorted, const uint16_t *sbucket, uint32_t total, const ChainDest &D,
+                                               BucketFn bucket_of, OvfFn overflow, StoreFn store) {
+  const int tid = threadIdx.x;
   // copy out, U elements per thread and trip: first all their records, then all their destinations, then the stores
   constexpr int U = NL == 1 ? 4 : 2;
   const size_t arena0 = (size_t)D.arena_base << D.log2CH;
@@ -385,9 +412,68 @@ __device__ __forceinline__ void l1_overflow(const Geom &gm, const BucketBufs &bb
   }
 }
 
+// ---- the run of a thread when k is known at compile time (compact records) -------------------------------------------
+// A thread's RPOS consecutive k-mers and their neighbours are RPOS + K + 1 <= 32 bases: one 64-bit window Wn of the
+// staged tile (first base highest), its reverse complement Rn, one 32-bit window each of the "usable as extension" bits
+// and of the read-boundary bits.  K-mer j with its two neighbours is then a (K+2)-base slice of Wn, and the same k-mer
+// read from the other strand -- neighbours complemented and swapped, exactly what S4/S5 ask for when the reverse
+// complement is the canonical form -- is the mirrored slice of Rn: every shift is a constant, nothing is rolled.
+// Outputs, in the short register form of split_stage: lo[j] = the low 32 bits of the mixed k-mer (with the bucket, its
+// top la >= 2K - 32 bits, that is all of it), bk[j] = bucket | extension codes << 10, or ~0 where there is no k-mer
+// (a code >= 4 means "none"; here a missing extension keeps the base in its low bits, which every consumer ignores).
+template <int K, int RPOS, bool SH, class TL>
+__device__ __forceinline__ void cp_run_fixed(const TL &L, int lp0, bool active, const Geom &gm, const ExtractArgs &a, uint32_t (&lo)[RPOS],
+                                             uint32_t (&bk)[RPOS]) {
+  constexpr int NB = RPOS + K + 1;
+  static_assert(NB <= 32 && RPOS % 8 == 0 && PRE % 8 == 0, "the window must fit one word and never start word-aligned");
+  const uint64_t *W = reinterpret_cast<const uint64_t *>(L.codes);
+  const uint32_t *OK = reinterpret_cast<const uint32_t *>(L.ok);
+  const int p = lp0 - 1, q = p >> 5, s = p & 31;  // lp0 is a multiple of 8: s is 7, 15, 23 or 31, never 0
+  const uint64_t w0 = W[q], w1 = W[q + 1];
+  const uint32_t ok0 = OK[q], ok1 = OK[q + 1], g0 = L.gap[q], g1 = L.gap[q + 1];
+  const uint64_t Wn = (w0 << (2 * s)) | (w1 >> (64 - 2 * s));
+  const uint32_t nok = ~__builtin_amdgcn_alignbit(ok1, ok0, (uint32_t)s);  // bit i: base i of the window is no extension
+  const uint32_t gapw = __builtin_amdgcn_alignbit(g1, g0, (uint32_t)s);    // bit i: read boundary before base i
+  const uint64_t Rn = kc_rc_word(Wn) << (64 - 2 * NB);
+  constexpr uint64_t MID = ((1ULL << (2 * K)) - 1ULL) << 2;  // the k-mer inside a slice
+  constexpr uint32_t MK = (1u << K) - 1u;
+#pragma unroll
+  for (int j = 0; j < RPOS; j++) {
+    const uint64_t x = Wn >> (64 - 2 * (j + K + 2)), y = Rn >> (64 - 2 * (RPOS - 1 - j + K + 2));
+    const bool swap = (y & MID) < (x & MID);  // strict: a palindrome keeps the forward extensions
+    const uint64_t sel = swap ? y : x;
+    // extension codes: the slice's outer bases, bit 2 set where the base may not serve as one
+    const uint32_t na = (nok >> j) & 1u, nb = (nok >> (j + K + 1)) & 1u;
+    const uint32_t le = ((uint32_t)(sel >> (2 * K + 2)) & 3u) | ((swap ? nb : na) << 2);
+    const uint32_t re = ((uint32_t)sel & 3u) | ((swap ? na : nb) << 2);
+    // the invertible mix of the k-mer (kc_feistel_fwd with constant k)
+    uint32_t Lh = (uint32_t)(sel >> (K + 2)) & MK, Rh = (uint32_t)(sel >> 2) & MK;
+    bool valid = active && ((gapw >> (j + 1)) & ((1u << (K + 1)) - 1u)) == 0u;
+    if (SH) {
+      uint64_t key[1] = {(((uint64_t)Lh << K) | Rh) << (64 - 2 * K)};
+      const uint32_t owner = a.reference_owner ? 0u : kc_owner_of_hash(kc_hash<1>(key), a.rank_n);
+      if (a.reference_owner) {
+        uint64_t rk[1];
+        kc_revcomp<1>(key, K, rk);
+        valid = valid && kc_reference_owner<1>(key, rk, K, a.rank_n) == a.rank_me;
+      } else {
+        valid = valid && owner == a.rank_me;
+      }
+    }
+    Lh ^= kc_feistel_f(Rh, 0, K);
+    Rh ^= kc_feistel_f(Lh, 1, K);
+    Lh ^= kc_feistel_f(Rh, 2, K);
+    Rh ^= kc_feistel_f(Lh, 3, K);
+    const uint64_t mix = ((uint64_t)Lh << K) | Rh;
+    lo[j] = (uint32_t)mix;
+    bk[j] = valid ? ((uint32_t)(mix >> (2 * K - gm.la)) | (le << 10) | (re << 13)) : ~0u;
+  }
+}
+
 // SH: the context is one shard of several and keeps only the k-mers it owns (kc_submit_reads with rank_n > 1); the
 // single-shard instantiation carries none of the ownership code.
-template <int NL, int FMT, bool CP, bool SH>
+// KK: k when the instantiation is made for one k (compact records only: cp_run_fixed), 0 = any k
+template <int NL, int FMT, bool CP, bool SH, int KK>
 __global__ __launch_bounds__(WGB) void kc_l1_reads_kernel(ExtractArgs a, Geom gm, BucketBufs bb, uint64_t nsuper, uint32_t rot,
                                                           uint64_t *ctrs, uint64_t *cb) {
   extern __shared__ __align__(16) uint8_t smem[];
@@ -418,60 +504,90 @@ __global__ __launch_bounds__(WGB) void kc_l1_reads_kernel(ExtractArgs a, Geom gm
   uint64_t next_first = first_of((uint64_t)blockIdx.x + gridDim.x);
   constexpr int RUNS = SUPER_SPAN / RPOS;  // runs of RPOS consecutive positions in a super-tile
   static_assert(SUPER_SPAN % RPOS == 0, "runs must tile the span");
-  for (uint64_t st = blockIdx.x; st < nsuper; st += gridDim.x) {
-    const int64_t T0 = a.pos0 + (int64_t)st * SUPER_SPAN;
-    tile_encode<FMT, TileSuper>(L.tile, raw, a, T0, ctrs, tid, true);
-    {
-      const uint64_t nst = st + gridDim.x;
-      tile_prefetch<FMT, TileSuper>(raw, a, a.pos0 + (int64_t)nst * SUPER_SPAN, tid, next_first, nst < nsuper);
-      next_first = first_of(nst + gridDim.x);
-    }
-    KC_SPLIT_STAMP(5)  // stage the super-tile
+  constexpr int NROUND = (RUNS + WGB - 1) / WGB;
+  // Iteration -1 only stages the first super-tile; every further one is staged in the middle of its predecessor's last
+  // round (one place in the code for the staging, one for the rounds: inlined twice they cost registers)
+  for (int64_t it = -1;; it++) {
+    const uint64_t st = (uint64_t)blockIdx.x + (uint64_t)(it < 0 ? 0 : it) * gridDim.x;
+    const bool work = it >= 0;  // the same for every thread of the workgroup
+    if (work && st >= nsuper) break;
 #pragma unroll 1
-    for (int round = 0; round < (RUNS + WGB - 1) / WGB; round++) {
-      uint64_t rec[RPOS][NL];
+    for (int round = 0; round < NROUND; round++) {
+      constexpr bool SHORT = KK != 0;  // records in the short register form
+      uint64_t rec[SHORT ? 1 : RPOS][NL];
+      uint32_t lo[SHORT ? RPOS : 1];
       uint32_t br[RPOS];
+      uint32_t total = 0;
+      if (work) {
       // each thread walks RPOS consecutive positions
       const int run_id = round * WGB + tid;
       const bool active = run_id < RUNS;
       const int lp0 = PRE + (active ? run_id : 0) * RPOS;
-      KmerRun<NL> run;
-      run_begin<NL>(run, L.tile, lp0, a.k);
+      if constexpr (KK != 0) {
+        static_assert(NL == 1 && CP, "a fixed k goes with compact records");
+        cp_run_fixed<KK, RPOS, SH>(L.tile, lp0, active, gm, a, lo, br);
+      } else {
+        KmerRun<NL> run;
+        run_begin<NL>(run, L.tile, lp0, a.k);
 #pragma unroll
-      for (int j = 0; j < RPOS; j++) {
-        uint64_t h = 0;
-        uint32_t owner = 0;
-        bool valid = run_kmer<NL, !CP>(run, j, lp0, a.k, rec[j], h, SH ? a.rank_n : 1u, SH ? a.reference_owner : 0u, SH ? &owner : nullptr) && active;
-        if (SH) {
-          if (CP && !a.reference_owner) {
-            uint64_t key[NL];
+        for (int j = 0; j < RPOS; j++) {
+          uint64_t h = 0;
+          uint32_t owner = 0;
+          bool valid = run_kmer<NL, !CP>(run, j, lp0, a.k, rec[j], h, SH ? a.rank_n : 1u, SH ? a.reference_owner : 0u, SH ? &owner : nullptr) && active;
+          if (SH) {
+            if (CP && !a.reference_owner) {
+              uint64_t key[NL];
 #pragma unroll
-            for (int w = 0; w < NL; w++) key[w] = rec[j][w];
-            key[NL - 1] &= ~KC_EXT_MASK;
-            owner = kc_owner_of_hash(kc_hash<NL>(key), a.rank_n);
+              for (int w = 0; w < NL; w++) key[w] = rec[j][w];
+              key[NL - 1] &= ~KC_EXT_MASK;
+              owner = kc_owner_of_hash(kc_hash<NL>(key), a.rank_n);
+            }
+            valid = valid && owner == a.rank_me;
           }
-          valid = valid && owner == a.rank_me;
+          if (CP) rec[j][0] = cp_mix_rec(rec[j][0], gm);
+          br[j] = valid ? (CP ? cp_b1(rec[j][0], gm) : hash_b1(h, gm)) : ~0u;
+          if (j + 1 < RPOS) run_advance<NL>(run, j, lp0, a.k);
         }
-        if (CP) rec[j][0] = cp_mix_rec(rec[j][0], gm);
-        br[j] = valid ? (CP ? cp_b1(rec[j][0], gm) : hash_b1(h, gm)) : ~0u;
-        if (j + 1 < RPOS) run_advance<NL>(run, j, lp0, a.k);
       }
       // the ranks: one LDS add per record, all of a thread's adds in flight together (no branch around them: a
       // position without a k-mer bumps a word of its own lane's instead)
 #pragma unroll
       for (int j = 0; j < RPOS; j++) {
         const bool valid = br[j] != ~0u;
-        const uint32_t rank = atomicAdd(valid ? &L.sp.hist[buf][br[j]] : &L.idle[lane_id()], 1u);
-        br[j] = valid ? (br[j] | (rank << 10)) : ~0u;
+        const uint32_t rank = atomicAdd(valid ? &L.sp.hist[buf][br[j] & (PMAX - 1)] : &L.idle[lane_id()], 1u);
+        br[j] = valid ? (br[j] | (rank << (SHORT ? 16 : 10))) : ~0u;
         n_ins += valid ? 1u : 0u;
       }
       KC_SPLIT_STAMP(0)  // cut the k-mers out of the super-tile, histogram
       lds_barrier();
-      split_round<NL, RPOS>(
-          L.sp, sorted, sbucket, buf, P1, rec, br, D, cst, [&](const uint64_t (&r)[NL]) { return cp_b1(r[0], gm); },
-          [&](uint32_t, const uint64_t (&r)[NL]) { l1_overflow<NL, CP>(gm, bb, cb, r); },
-          [&](size_t i, const uint64_t (&r)[NL]) { store_words<NL>(D.arena, i, r); });
-      buf ^= 1;
+      total = split_stage<NL, RPOS, SHORT ? 16 : 10>(
+          L.sp, sorted, sbucket, buf, P1,
+          [&](int j, uint64_t (&o)[NL]) {
+            if constexpr (SHORT) {
+              o[0] = ((uint64_t)(br[j] & (PMAX - 1)) << (64u - gm.la)) | ((uint64_t)lo[j] << (64u - gm.k2)) | (uint64_t)((br[j] >> 10) & 63u);
+            } else {
+#pragma unroll
+              for (int w = 0; w < NL; w++) o[w] = rec[j][w];
+            }
+          },
+          br, D, cst);
+      }
+      if (round == NROUND - 1) {
+        // Every k-mer of this super-tile has left it (the barrier after the histogram): stage the next one now, between
+        // scatter and copy-out (split_stage's comment)
+        const uint64_t nst = work ? st + gridDim.x : st;
+        tile_encode<FMT, TileSuper>(L.tile, raw, a, a.pos0 + (int64_t)nst * SUPER_SPAN, ctrs, tid, nst < nsuper);
+        tile_prefetch<FMT, TileSuper>(raw, a, a.pos0 + (int64_t)(nst + gridDim.x) * SUPER_SPAN, tid, next_first, nst + gridDim.x < nsuper);
+        next_first = first_of(nst + 2 * (uint64_t)gridDim.x);
+        KC_SPLIT_STAMP(5)  // stage the next super-tile
+      }
+      if (work) {
+        split_copy_out<NL>(
+            L.sp, sorted, sbucket, total, D, [&](const uint64_t (&r)[NL]) { return cp_b1(r[0], gm); },
+            [&](uint32_t, const uint64_t (&r)[NL]) { l1_overflow<NL, CP>(gm, bb, cb, r); },
+            [&](size_t i, const uint64_t (&r)[NL]) { store_words<NL>(D.arena, i, r); });
+        buf ^= 1;
+      }
     }
   }
   if ((uint32_t)tid < P1) bb.cnt1[(size_t)g * P1 + tid] = cst.cur;
@@ -591,6 +707,7 @@ __global__ __launch_bounds__(WGB) void kc_bin_reads_kernel(ExtractArgs a, uint64
 // ---- level 1 from records (receiver side of the shard exchange) -------------------------------------
 struct L1RLDS {
   SplitLDS sp;
+  uint32_t idle[64];  // what the lanes past the end add to (one word per lane)
 };
 
 template <int NL, bool CP>
@@ -604,6 +721,7 @@ __global__ __launch_bounds__(WGB) void kc_l1_records_kernel(const uint64_t *recs
   const uint32_t g = (blockIdx.x + rot) % gm.G, P1 = gm.P1;
   const ChainDest D = l1_dest<NL>(gm, bb, g);
   ChainState cst = split_load_state(L.sp, P1, bb.cnt1 + (size_t)g * P1, D.chain, D.LMAX, D.log2CH, bb.used1[g]);
+  if (tid < 64) L.idle[tid] = 0;
   __syncthreads();
   const uint64_t per_round = (uint64_t)WGB * RPOS;
   const uint64_t nrounds = (n + per_round - 1) / per_round;
@@ -620,31 +738,42 @@ __global__ __launch_bounds__(WGB) void kc_l1_records_kernel(const uint64_t *recs
       for (int w = 0; w < NL; w++) nxt[j][w] = recs[i * NL + w];
     }
   };
+  // rec: this round's records; nxt: the next round's, taken over in the middle of the round (split_stage's comment)
+  uint64_t rec[RPOS][NL];
   if (n) load_round(blockIdx.x);
+#pragma unroll
+  for (int j = 0; j < RPOS; j++)
+#pragma unroll
+    for (int w = 0; w < NL; w++) rec[j][w] = nxt[j][w];
+  if (n) load_round((uint64_t)blockIdx.x + gridDim.x);
   for (uint64_t rd = blockIdx.x; rd < nrounds; rd += gridDim.x) {
-    uint64_t rec[RPOS][NL];
     uint32_t br[RPOS];
+    // all the ranks of a thread in flight together (no branch around the LDS adds: a lane past the end, which holds a
+    // copy of the last record, bumps a word of its own lane's instead)
+#pragma unroll
+    for (int j = 0; j < RPOS; j++) {
+      const bool valid = rd * per_round + (uint64_t)j * WGB + tid < n;
+      if (CP) rec[j][0] = cp_mix_rec(rec[j][0], gm);
+      const uint32_t b = CP ? cp_b1(rec[j][0], gm) : hash_b1(rec_hash<NL>(rec[j]), gm);
+      const uint32_t rank = atomicAdd(valid ? &L.sp.hist[buf][b] : &L.idle[lane_id()], 1u);
+      br[j] = valid ? (b | (rank << 10)) : ~0u;
+      n_ins += valid ? 1u : 0u;
+    }
+    lds_barrier();
+    const uint32_t total = split_stage<NL, RPOS>(
+        L.sp, sorted, nullptr, buf, P1,
+        [&](int j, uint64_t (&o)[NL]) {
+#pragma unroll
+          for (int w = 0; w < NL; w++) o[w] = rec[j][w];
+        },
+        br, D, cst);
 #pragma unroll
     for (int j = 0; j < RPOS; j++)
 #pragma unroll
       for (int w = 0; w < NL; w++) rec[j][w] = nxt[j][w];
-    load_round(rd + gridDim.x);
-#pragma unroll
-    for (int j = 0; j < RPOS; j++) {
-      const uint64_t i = rd * per_round + (uint64_t)j * WGB + tid;
-      br[j] = ~0u;
-      if (i < n) {
-        if (CP) rec[j][0] = cp_mix_rec(rec[j][0], gm);
-        const uint32_t b = CP ? cp_b1(rec[j][0], gm) : hash_b1(rec_hash<NL>(rec[j]), gm);
-        const uint32_t rank = atomicAdd(&L.sp.hist[buf][b], 1u);
-        br[j] = b | (rank << 10);
-        n_ins++;
-      }
-    }
-    lds_barrier();
-    split_round<NL, RPOS>(
-        L.sp, sorted, nullptr, buf, P1, rec, br, D, cst,
-        [&](const uint64_t (&r)[NL]) { return CP ? cp_b1(r[0], gm) : hash_b1(rec_hash<NL>(r), gm); },
+    load_round(rd + 2 * (uint64_t)gridDim.x);
+    split_copy_out<NL>(
+        L.sp, sorted, nullptr, total, D, [&](const uint64_t (&r)[NL]) { return CP ? cp_b1(r[0], gm) : hash_b1(rec_hash<NL>(r), gm); },
         [&](uint32_t, const uint64_t (&r)[NL]) { l1_overflow<NL, CP>(gm, bb, cb, r); },
         [&](size_t i, const uint64_t (&r)[NL]) { store_words<NL>(D.arena, i, r); });
     buf ^= 1;
@@ -701,17 +830,22 @@ __global__ __launch_bounds__(WGB) void kc_bucket_prefix_kernel(Geom gm, BucketBu
 struct L2LDS {
   SplitLDS sp;
   uint32_t pre[GMAX + 1];  // prefix of the bucket's G segment lengths
+  uint32_t idle[64];       // what the lanes past the end add to (one word per lane)
 };
 
 // CP: the records are mixed ones; what leaves for the regions is their 32-bit remainder (cp_pack32)
-template <int NL, bool CP>
+// CR: compact records whose mix fits 32 bits below the bucket (2k - la <= 32) are kept in the short register form of
+// split_stage between the rounds (half the registers of the full records)
+template <int NL, bool CP, bool CR>
 __global__ __launch_bounds__(WGB) void kc_l2_split_kernel(Geom gm, BucketBufs bb, uint64_t *cb) {
+  static_assert(!CR || (CP && NL == 1), "the short form is one of compact records");
   extern __shared__ __align__(16) uint8_t smem[];
   L2LDS &L = *reinterpret_cast<L2LDS *>(smem);
   uint64_t *sorted = reinterpret_cast<uint64_t *>(smem + ((sizeof(L2LDS) + 15) & ~size_t(15)));
   constexpr int RPOS = Rnd<NL>::RPOS;
   const int tid = threadIdx.x;
   const uint32_t P1 = gm.P1, P2 = gm.P2, G = gm.G;
+  if (tid < 64) L.idle[tid] = 0;
   for (uint32_t b1 = blockIdx.x; b1 < P1; b1 += gridDim.x) {
     // prefix over the G segments of this bucket
     {
@@ -761,31 +895,59 @@ __global__ __launch_bounds__(WGB) void kc_l2_split_kernel(Geom gm, BucketBufs bb
         for (int w = 0; w < NL; w++) nxt[j][w] = src[w];
       }
     };
-    if (n) load_round(0);
-    int buf = 0;
-    for (uint32_t v0 = 0; v0 < n; v0 += per_round) {
-      uint64_t rec[RPOS][NL];
-      uint32_t br[RPOS];
-#pragma unroll
-      for (int j = 0; j < RPOS; j++)
-#pragma unroll
-        for (int w = 0; w < NL; w++) rec[j][w] = nxt[j][w];
-      if (v0 + per_round < n) load_round(v0 + per_round);
+    // rec (or lo + br in the short form): this round's records; nxt: the next round's, taken over in the middle of the
+    // round (split_stage's comment)
+    uint64_t rec[CR ? 1 : RPOS][NL];
+    uint32_t lo[CR ? RPOS : 1];
+    uint32_t br[RPOS];
+    const uint32_t sh_b2 = gm.k2 - gm.la - gm.lb;  // CR: where the region's index starts in the mix
+    auto take_over = [&]() {
 #pragma unroll
       for (int j = 0; j < RPOS; j++) {
-        const uint32_t e = v0 + (uint32_t)j * WGB + tid;
-        br[j] = ~0u;
-        if (e < n) {
-          const uint32_t b = CP ? cp_b2(rec[j][0], gm) : hash_b2(rec_hash<NL>(rec[j]), gm);
-          const uint32_t rank = atomicAdd(&L.sp.hist[buf][b], 1u);
-          br[j] = b | (rank << 10);
+        if constexpr (CR) {
+          lo[j] = (uint32_t)(nxt[j][0] >> (64u - gm.k2));
+          br[j] = ((lo[j] >> sh_b2) & (P2 - 1u)) | (((uint32_t)nxt[j][0] & 63u) << 10);
+        } else {
+#pragma unroll
+          for (int w = 0; w < NL; w++) rec[j][w] = nxt[j][w];
         }
       }
-      KC_SPLIT_STAMP(0)  // wait for the records, issue the next loads, histogram
+    };
+    if (n) load_round(0);
+    take_over();
+    if (per_round < n) load_round(per_round);
+    int buf = 0;
+    for (uint32_t v0 = 0; v0 < n; v0 += per_round) {
+      // all the ranks of a thread in flight together (no branch around the LDS adds: a lane past the end, which holds
+      // a copy of the bucket's last record, bumps a word of its own lane's instead)
+#pragma unroll
+      for (int j = 0; j < RPOS; j++) {
+        const bool valid = v0 + (uint32_t)j * WGB + tid < n;
+        uint32_t b;
+        if constexpr (CR) b = br[j] & (PMAX - 1);
+        else b = CP ? cp_b2(rec[j][0], gm) : hash_b2(rec_hash<NL>(rec[j]), gm);
+        const uint32_t rank = atomicAdd(valid ? &L.sp.hist[buf][b] : &L.idle[lane_id()], 1u);
+        if constexpr (CR) br[j] = valid ? (br[j] | (rank << 16)) : ~0u;
+        else br[j] = valid ? (b | (rank << 10)) : ~0u;
+      }
+      KC_SPLIT_STAMP(0)  // histogram
       lds_barrier();
-      split_round<NL, RPOS>(
-          L.sp, sorted, nullptr, buf, P2, rec, br, D, cst,
-          [&](const uint64_t (&r)[NL]) { return CP ? cp_b2(r[0], gm) : hash_b2(rec_hash<NL>(r), gm); },
+      const uint32_t total = split_stage<NL, RPOS, CR ? 16 : 10>(
+          L.sp, sorted, nullptr, buf, P2,
+          [&](int j, uint64_t (&o)[NL]) {
+            if constexpr (CR) {
+              o[0] = ((uint64_t)b1 << (64u - gm.la)) | ((uint64_t)lo[j] << (64u - gm.k2)) | (uint64_t)((br[j] >> 10) & 63u);
+            } else {
+#pragma unroll
+              for (int w = 0; w < NL; w++) o[w] = rec[j][w];
+            }
+          },
+          br, D, cst);
+      take_over();
+      if (v0 + 2 * (uint64_t)per_round < n) load_round(v0 + 2 * per_round);
+      KC_SPLIT_STAMP(5)  // take over the next round's records, request the one after
+      split_copy_out<NL>(
+          L.sp, sorted, nullptr, total, D, [&](const uint64_t (&r)[NL]) { return CP ? cp_b2(r[0], gm) : hash_b2(rec_hash<NL>(r), gm); },
           [&](uint32_t b, const uint64_t (&r)[NL]) {
             bb.flag[(size_t)b1 * P2 + b] = 1;
             const uint64_t o = atomicAdd((unsigned long long *)&cb[CB_OVF2], 1ULL);

@@ -14,6 +14,7 @@
 
 #include <algorithm>
 #include <new>
+#include <thread>
 #include <vector>
 
 #include "../../include/kcount_mi355.h"
@@ -62,10 +63,20 @@ struct kc_ctx {
   uint64_t *d_tile_first;
   uint64_t *d_out_plan;  // hole-closing plan + per-workgroup tails of the block-wise result output
   size_t tile_first_cap;
-  // staging for host-resident input
+  // staging for host-resident input (single slot: the '_'-joined blocks of kc_submit_seq_block)
   uint8_t *d_stage_bases, *d_stage_quals;
   uint64_t *d_stage_offsets;
   size_t stage_bytes, stage_reads;
+  // host-resident reads: two device slots and two pinned host slots, copies on a stream of their own (host_pipe_*)
+  struct {
+    uint8_t *d_bases[2], *d_quals[2], *h_bases[2], *h_quals[2];
+    uint64_t *d_offs[2], *h_offs[2];
+    hipEvent_t copied[2], consumed[2];
+    bool used[2];
+    hipStream_t copy_stream;
+    size_t cap_bytes, cap_reads;
+    bool ready;
+  } hp;
   // results
   uint64_t *d_out_keys;
   uint16_t *d_out_counts;
@@ -97,6 +108,7 @@ struct kc_ctx {
 
 // ---- kernel timing (HIP events on the launch stream) --------------------------------------------
 static void bk_free(kc_ctx *c);
+static void host_pipe_free(kc_ctx *c);
 
 struct KernelTimer {
   kc_ctx *c;
@@ -366,6 +378,7 @@ extern "C" void kc_destroy(kc_ctx *c) {
   if (c->d_stage_quals) (void)hipFree(c->d_stage_quals);
   if (c->d_stage_offsets) (void)hipFree(c->d_stage_offsets);
   if (c->d_synth) (void)hipFree(c->d_synth);
+  host_pipe_free(c);
   bk_free(c);
   if (c->d_cb) (void)hipFree(c->d_cb);
   if (c->h_cb) (void)hipHostFree(c->h_cb);
@@ -517,7 +530,10 @@ static int bk_init(kc_ctx *c) {
   g.A2 = (uint32_t)a2;
   BucketBufs &b = c->bb;
   memset(&b, 0, sizeof(b));
-  b.ovf1_cap = b.ovf2_cap = t.ovf_capacity ? t.ovf_capacity : bcap / 16 + 4096;
+  // Overflow lists: a quarter (one-word records) or an eighth of the buffer each.  Neither can lose a record: every
+  // level-1 launch is bounded by the free room of the first (bk_ovf1_room), and level 2 is run again with a larger
+  // second list when that one was too small (bk_build_regions).
+  b.ovf1_cap = b.ovf2_cap = t.ovf_capacity ? t.ovf_capacity : bcap / (c->nl == 1 ? 4 : 8) + 4096;
   const size_t w = (size_t)c->nl * 8;
   const size_t nseg = (size_t)g.G * g.P1;
   const size_t rec1_bytes = (size_t)g.G * g.A1 * CH1 * w, rec2_bytes = (size_t)g.A2 * CH2 * (g.cp ? 4 : w);
@@ -548,6 +564,46 @@ static int bk_init(kc_ctx *c) {
 static int sync_cb(kc_ctx *c) {
   HIPCHK(hipMemcpyAsync(c->h_cb, c->d_cb, CB_COUNT * 8, hipMemcpyDeviceToHost, c->stream));
   HIPCHK(hipStreamSynchronize(c->stream));
+  return KC_OK;
+}
+
+static int ensure_room(kc_ctx *c, uint64_t incoming);
+
+template <int NL>
+static void launch_ovf1_drain(kc_ctx *c, uint64_t n) {
+  auto kern = (NL == 1 && c->gm.cp) ? kc_ovf1_drain_kernel<NL, NL == 1> : kc_ovf1_drain_kernel<NL, false>;
+  hipLaunchKernelGGL(kern, dim3((unsigned)std::min<uint64_t>((n + TPB - 1) / TPB, 256 * 32)), dim3(TPB), 0, c->stream, c->gm, c->bb, n,
+                     c->table, c->d_ctrs);
+}
+
+// Records the level-1 overflow list can still take.  A launch over `want` k-mer positions can overflow at most that
+// many records: when the list has less room than that and holds something, its records are moved to the global table
+// first (syncs the stream).  The caller bounds its launch by the returned room.
+static int bk_ovf1_room(kc_ctx *c, uint64_t want, uint64_t *room) {
+  int rc = sync_cb(c);
+  if (rc) return rc;
+  if (c->h_cb[CB_FATAL]) {
+    snprintf(g_last_error, sizeof(g_last_error), "k-mer buffer: records were lost (fatal bits %llu)", (unsigned long long)c->h_cb[CB_FATAL]);
+    return KC_ERR_CAPACITY;
+  }
+  uint64_t used = std::min<uint64_t>(c->h_cb[CB_OVF1], c->bb.ovf1_cap);
+  if (used && c->bb.ovf1_cap - used < want) {
+    rc = ensure_room(c, used);
+    if (rc) return rc;
+    {
+      KernelTimer kt(c, KT_FALLBACK);
+      switch (c->nl) {
+        case 1: launch_ovf1_drain<1>(c, used); break;
+        case 2: launch_ovf1_drain<2>(c, used); break;
+        case 3: launch_ovf1_drain<3>(c, used); break;
+        default: launch_ovf1_drain<4>(c, used); break;
+      }
+    }
+    HIPCHK(hipGetLastError());
+    HIPCHK(hipMemsetAsync(c->d_cb + CB_OVF1, 0, 8, c->stream));
+    used = 0;
+  }
+  *room = c->bb.ovf1_cap - used;
   return KC_OK;
 }
 
@@ -800,11 +856,21 @@ static int run_extract_device(kc_ctx *c, const uint8_t *bases, const uint8_t *qu
       chunk_tiles = std::max<uint64_t>(64, (c->capacity / 4) / span);
       chunk_tiles = std::min<uint64_t>(chunk_tiles, (1ULL << 28) / span);
     }
-    const uint64_t nt = std::min<uint64_t>(chunk_tiles, ((uint64_t)(end - p0) + span - 1) / span);
+    uint64_t nt = std::min<uint64_t>(chunk_tiles, ((uint64_t)(end - p0) + span - 1) / span);
     if (bk && over_capacity) {
       int rc = bk_drain_to_table(c);  // out of buffer room: this and every later chunk take the table path
       if (rc) return rc;
       continue;
+    }
+    if (bk) {  // no launch may overflow more records than the overflow list has room for
+      uint64_t room = 0;
+      int rc = bk_ovf1_room(c, nt * span, &room);
+      if (rc) return rc;
+      nt = std::max<uint64_t>(1, std::min<uint64_t>(nt, room / span));
+      if (room < span) {  // a list smaller than one super-tile (test geometries only): nothing is bounded by it
+        snprintf(g_last_error, sizeof(g_last_error), "overflow list smaller than one tile of %llu positions: raise ovf_capacity", (unsigned long long)span);
+        return KC_ERR_CAPACITY;
+      }
     }
     if (mode == MODE_INSERT && !bk) {
       int rc = ensure_room(c, nt * span);
@@ -868,6 +934,160 @@ static int ensure_stage(kc_ctx *c, size_t bytes, size_t reads, bool need_quals) 
   return KC_OK;
 }
 
+// ---- host-resident reads: overlapped staging ---------------------------------------------------------------------
+// The reference overlaps parsing with communication progress on a worker thread (src/kcount/kcount_gpu.cpp:119-133).
+// Here the reads cross PCIe in blocks of HOST_BLOCK bytes of bases (+ as many of qualities): block i+1 is copied by a
+// stream of its own while block i is extracted, events order the two streams, and the host never waits for a copy it
+// has just issued.  Memory the caller has pinned (hipHostMalloc / hipHostRegister) is copied from where it lies;
+// pageable memory goes through two pinned slots filled by a few threads (one thread's memcpy is slower than the link).
+// KC_HOST_BLOCK (bytes) in the environment overrides the block size: tests use it to push small inputs through many blocks
+static size_t host_block_bytes() {
+  const char *e = getenv("KC_HOST_BLOCK");
+  const unsigned long long x = e ? strtoull(e, nullptr, 10) : 0;
+  return x >= 4096 ? (size_t)x : ((size_t)256 << 20);
+}
+
+static void host_pipe_free(kc_ctx *c) {
+  auto &h = c->hp;
+  for (int s = 0; s < 2; s++) {
+    if (h.d_bases[s]) (void)hipFree(h.d_bases[s]);
+    if (h.d_quals[s]) (void)hipFree(h.d_quals[s]);
+    if (h.d_offs[s]) (void)hipFree(h.d_offs[s]);
+    if (h.h_bases[s]) (void)hipHostFree(h.h_bases[s]);
+    if (h.h_quals[s]) (void)hipHostFree(h.h_quals[s]);
+    if (h.h_offs[s]) (void)hipHostFree(h.h_offs[s]);
+    if (h.copied[s]) (void)hipEventDestroy(h.copied[s]);
+    if (h.consumed[s]) (void)hipEventDestroy(h.consumed[s]);
+  }
+  if (h.copy_stream) (void)hipStreamDestroy(h.copy_stream);
+  memset(&h, 0, sizeof(h));
+}
+
+static int host_pipe_init(kc_ctx *c, size_t bytes, size_t reads, bool pinned_source) {
+  auto &h = c->hp;
+  if (h.ready && h.cap_bytes >= bytes && h.cap_reads >= reads && (pinned_source || h.h_bases[0])) return KC_OK;
+  host_pipe_free(c);
+  HIPCHK(hipStreamCreateWithFlags(&h.copy_stream, hipStreamNonBlocking));
+  for (int s = 0; s < 2; s++) {
+    HIPCHK(hipMalloc((void **)&h.d_bases[s], bytes + 64));
+    HIPCHK(hipMalloc((void **)&h.d_quals[s], bytes + 64));
+    HIPCHK(hipMalloc((void **)&h.d_offs[s], (reads + 1) * 8));
+    HIPCHK(hipHostMalloc((void **)&h.h_offs[s], (reads + 1) * 8, hipHostMallocDefault));
+    if (!pinned_source) {
+      HIPCHK(hipHostMalloc((void **)&h.h_bases[s], bytes, hipHostMallocDefault));
+      HIPCHK(hipHostMalloc((void **)&h.h_quals[s], bytes, hipHostMallocDefault));
+    }
+    HIPCHK(hipEventCreateWithFlags(&h.copied[s], hipEventDisableTiming));
+    HIPCHK(hipEventCreateWithFlags(&h.consumed[s], hipEventDisableTiming));
+  }
+  h.cap_bytes = bytes;
+  h.cap_reads = reads;
+  h.ready = true;
+  return KC_OK;
+}
+
+static bool is_pinned_host(const void *p) {
+  hipPointerAttribute_t at;
+  if (hipPointerGetAttributes(&at, p) != hipSuccess) {
+    (void)hipGetLastError();  // pageable memory the runtime has never seen: not an error
+    return false;
+  }
+  return at.type == hipMemoryTypeHost;
+}
+
+static void parallel_copy(uint8_t *dst, const uint8_t *src, size_t n) {
+  const unsigned hw = std::thread::hardware_concurrency();
+  const size_t nt = std::max<size_t>(1, std::min<size_t>({(size_t)8, (size_t)(hw ? hw / 2 : 2), n >> 22}));
+  if (nt == 1) {
+    memcpy(dst, src, n);
+    return;
+  }
+  std::vector<std::thread> th;
+  const size_t per = (n + nt - 1) / nt;
+  for (size_t t = 0; t < nt; t++) {
+    const size_t o = t * per;
+    if (o >= n) break;
+    th.emplace_back([=]() { memcpy(dst + o, src + o, std::min(per, n - o)); });
+  }
+  for (auto &t : th) t.join();
+}
+
+static int submit_host_reads(kc_ctx *c, const uint8_t *bases, const uint8_t *quals, const uint64_t *offsets, uint64_t nreads, int mode,
+                             uint64_t *d_records, uint64_t seg_capacity, int fmt) {
+  const size_t HOST_BLOCK = host_block_bytes();
+  const bool with_quals = fmt == FMT_READS;
+  const bool pinned = is_pinned_host(bases) && (!with_quals || is_pinned_host(quals));
+  // blocks of whole reads: at most HOST_BLOCK bytes, and a single read that is longer gets a block of its own
+  size_t max_bytes = 0, max_reads = 0;
+  {
+    uint64_t r0 = 0;
+    while (r0 < nreads) {
+      uint64_t r1 = r0 + 1;
+      while (r1 < nreads && offsets[r1 + 1] - offsets[r0] <= HOST_BLOCK) r1++;
+      max_bytes = std::max<size_t>(max_bytes, (size_t)(offsets[r1] - offsets[r0]));
+      max_reads = std::max<size_t>(max_reads, (size_t)(r1 - r0));
+      r0 = r1;
+    }
+  }
+  int rc = host_pipe_init(c, max_bytes, max_reads, pinned);
+  if (rc) return rc;
+  auto &h = c->hp;
+  struct Blk { uint64_t r0, r1; };
+  auto next_block = [&](uint64_t r0) {
+    uint64_t r1 = r0 + 1;
+    while (r1 < nreads && offsets[r1 + 1] - offsets[r0] <= HOST_BLOCK) r1++;
+    return Blk{r0, r1};
+  };
+  // stage: host side of one block + its copies (asynchronous, on the copy stream)
+  auto stage = [&](int s, const Blk &b) -> int {
+    if (h.used[s]) HIPCHK(hipEventSynchronize(h.consumed[s]));  // the kernels of two blocks ago have read slot s
+    const uint64_t nb = offsets[b.r1] - offsets[b.r0], nr = b.r1 - b.r0;
+    for (uint64_t i = 0; i <= nr; i++) h.h_offs[s][i] = offsets[b.r0 + i] - offsets[b.r0];
+    const uint8_t *sb = bases + offsets[b.r0], *sq = with_quals ? quals + offsets[b.r0] : nullptr;
+    if (!pinned) {
+      parallel_copy(h.h_bases[s], sb, nb);
+      sb = h.h_bases[s];
+      if (with_quals) {
+        parallel_copy(h.h_quals[s], sq, nb);
+        sq = h.h_quals[s];
+      }
+    }
+    HIPCHK(hipMemcpyAsync(h.d_bases[s], sb, nb, hipMemcpyHostToDevice, h.copy_stream));
+    if (with_quals) HIPCHK(hipMemcpyAsync(h.d_quals[s], sq, nb, hipMemcpyHostToDevice, h.copy_stream));
+    HIPCHK(hipMemcpyAsync(h.d_offs[s], h.h_offs[s], (nr + 1) * 8, hipMemcpyHostToDevice, h.copy_stream));
+    HIPCHK(hipEventRecord(h.copied[s], h.copy_stream));
+    h.used[s] = true;
+    return KC_OK;
+  };
+  Blk cur = next_block(0);
+  rc = stage(0, cur);
+  if (rc) return rc;
+  for (int i = 0;; i++) {
+    const int s = i & 1;
+    const bool more = cur.r1 < nreads;
+    Blk nxt{0, 0};
+    if (more) {  // the next block's copy is under way before this block's kernels are even launched
+      nxt = next_block(cur.r1);
+      rc = stage(s ^ 1, nxt);
+      if (rc) return rc;
+    }
+    const uint64_t nb = offsets[cur.r1] - offsets[cur.r0], nr = cur.r1 - cur.r0;
+    HIPCHK(hipStreamWaitEvent(c->stream, h.copied[s], 0));
+    rc = raw_kmer_stats(c, h.d_offs[s], nr, mode);
+    if (rc) return rc;
+    rc = run_extract_device(c, h.d_bases[s], h.d_quals[s], h.d_offs[s], nr, nb, mode, fmt, d_records, seg_capacity);
+    if (rc) return rc;
+    HIPCHK(hipEventRecord(h.consumed[s], c->stream));
+    c->num_reads += nr;
+    c->num_bases += nb;
+    if (!more) break;
+    cur = nxt;
+  }
+  // the caller's arrays are free to change once every copy has left them
+  HIPCHK(hipStreamSynchronize(h.copy_stream));
+  return KC_OK;
+}
+
 // reads (either residence) through extract in `mode`
 static int submit_reads_impl(kc_ctx *c, const uint8_t *bases, const uint8_t *quals, const uint64_t *offsets, uint64_t nreads,
                              int on_device, int mode, uint64_t *d_records, uint64_t seg_capacity, int fmt = FMT_READS) {
@@ -889,33 +1109,7 @@ static int submit_reads_impl(kc_ctx *c, const uint8_t *bases, const uint8_t *qua
     c->num_bases += ends[1];
     return KC_OK;
   }
-  // host-resident: stage blocks of whole reads
-  const size_t BLOCK = 64u << 20;
-  std::vector<uint64_t> rel;
-  uint64_t r0 = 0;
-  while (r0 < nreads) {
-    uint64_t r1 = r0 + 1;
-    while (r1 < nreads && offsets[r1 + 1] - offsets[r0] <= BLOCK) r1++;
-    const uint64_t nb = offsets[r1] - offsets[r0], nr = r1 - r0;
-    int rc = ensure_stage(c, (size_t)nb, (size_t)nr, true);
-    if (rc) return rc;
-    rel.resize(nr + 1);
-    for (uint64_t i = 0; i <= nr; i++) rel[i] = offsets[r0 + i] - offsets[r0];
-    // the previous block's kernels may still be reading the staging buffers
-    HIPCHK(hipStreamSynchronize(c->stream));
-    HIPCHK(hipMemcpyAsync(c->d_stage_bases, bases + offsets[r0], nb, hipMemcpyHostToDevice, c->stream));
-    if (fmt == FMT_READS) HIPCHK(hipMemcpyAsync(c->d_stage_quals, quals + offsets[r0], nb, hipMemcpyHostToDevice, c->stream));
-    HIPCHK(hipMemcpyAsync(c->d_stage_offsets, rel.data(), (nr + 1) * 8, hipMemcpyHostToDevice, c->stream));
-    HIPCHK(hipStreamSynchronize(c->stream));  // rel is reused next trip
-    rc = raw_kmer_stats(c, c->d_stage_offsets, nr, mode);
-    if (rc) return rc;
-    rc = run_extract_device(c, c->d_stage_bases, c->d_stage_quals, c->d_stage_offsets, nr, nb, mode, fmt, d_records, seg_capacity);
-    if (rc) return rc;
-    c->num_reads += nr;
-    c->num_bases += nb;
-    r0 = r1;
-  }
-  return KC_OK;
+  return submit_host_reads(c, bases, quals, offsets, nreads, mode, d_records, seg_capacity, fmt);
 }
 
 extern "C" int kc_submit_reads(kc_ctx *c, const uint8_t *bases, const uint8_t *quals, const uint64_t *offsets, uint64_t nreads,
@@ -1038,14 +1232,28 @@ extern "C" int kc_insert_records(kc_ctx *c, const uint64_t *d_records, uint64_t 
       rc = bk_drain_to_table(c);
       if (rc) return rc;
     } else {
-      switch (c->nl) {
-        case 1: rc = launch_l1_records_t<1>(c, d_records, n); break;
-        case 2: rc = launch_l1_records_t<2>(c, d_records, n); break;
-        case 3: rc = launch_l1_records_t<3>(c, d_records, n); break;
-        default: rc = launch_l1_records_t<4>(c, d_records, n); break;
+      // pieces no larger than the overflow list's free room (bk_ovf1_room)
+      uint64_t done = 0;
+      while (done < n) {
+        uint64_t room = 0;
+        rc = bk_ovf1_room(c, n - done, &room);
+        if (rc) return rc;
+        const uint64_t m = std::min<uint64_t>(n - done, room);
+        if (!m) {
+          snprintf(g_last_error, sizeof(g_last_error), "overflow list has no room: raise ovf_capacity");
+          return KC_ERR_CAPACITY;
+        }
+        const uint64_t *p = d_records + done * c->nl;
+        switch (c->nl) {
+          case 1: rc = launch_l1_records_t<1>(c, p, m); break;
+          case 2: rc = launch_l1_records_t<2>(c, p, m); break;
+          case 3: rc = launch_l1_records_t<3>(c, p, m); break;
+          default: rc = launch_l1_records_t<4>(c, p, m); break;
+        }
+        if (rc) return rc;
+        HIPCHK(hipGetLastError());
+        done += m;
       }
-      if (rc) return rc;
-      HIPCHK(hipGetLastError());
       return KC_OK;
     }
   }
@@ -1170,7 +1378,7 @@ static int bk_build_regions(kc_ctx *c) {
   int rc = sync_cb(c);
   if (rc) return rc;
   if (c->h_cb[CB_FATAL]) {
-    snprintf(g_last_error, sizeof(g_last_error), "k-mer buffer overflow lists exhausted: raise max_kmers_buffered");
+    snprintf(g_last_error, sizeof(g_last_error), "k-mer buffer: records were lost at level 1 (fatal bits %llu)", (unsigned long long)c->h_cb[CB_FATAL]);
     return KC_ERR_CAPACITY;
   }
 #ifdef KC_STAMPS
@@ -1183,13 +1391,33 @@ static int bk_build_regions(kc_ctx *c) {
           (unsigned long long)c->h_ctrs[CTR_BIN0 + 41], (unsigned long long)c->h_ctrs[CTR_BIN0 + 42], (unsigned long long)c->h_ctrs[CTR_BIN0 + 43]);
   HIPCHK(hipMemsetAsync(c->d_cb + 8, 0, 8 * 8, c->stream));
 #endif
-  switch (c->nl) {
-    case 1: rc = bk_level2_t<1>(c); break;
-    case 2: rc = bk_level2_t<2>(c); break;
-    case 3: rc = bk_level2_t<3>(c); break;
-    default: rc = bk_level2_t<4>(c); break;
+  for (int attempt = 0;; attempt++) {
+    switch (c->nl) {
+      case 1: rc = bk_level2_t<1>(c); break;
+      case 2: rc = bk_level2_t<2>(c); break;
+      case 3: rc = bk_level2_t<3>(c); break;
+      default: rc = bk_level2_t<4>(c); break;
+    }
+    if (rc) return rc;
+    rc = sync_cb(c);
+    if (rc) return rc;
+    const uint64_t fatal = c->h_cb[CB_FATAL];
+    if (!fatal) break;
+    if (fatal != FATAL_OVF2 || attempt > 0) {
+      snprintf(g_last_error, sizeof(g_last_error), "k-mer buffer: records were lost building the regions (fatal bits %llu)", (unsigned long long)fatal);
+      return KC_ERR_CAPACITY;
+    }
+    // The second overflow list was too small for the regions that outgrew their chains (heavy hitters).  Level 1 is
+    // untouched and the counter kept counting past the end, so it says exactly how much room the same pass needs.
+    const uint64_t need = c->h_cb[CB_OVF2] + c->h_cb[CB_OVF2] / 64 + 4096;
+    uint64_t *bigger = nullptr;
+    HIPCHK(hipMalloc((void **)&bigger, need * (size_t)c->nl * 8));
+    HIPCHK(hipFree(c->bb.ovf2));
+    c->bk_bytes += (need - c->bb.ovf2_cap) * (size_t)c->nl * 8;
+    c->bb.ovf2 = bigger;
+    c->bb.ovf2_cap = need;
+    HIPCHK(hipMemsetAsync(c->d_cb + CB_OVF2, 0, 2 * 8, c->stream));  // OVF2, FATAL
   }
-  if (rc) return rc;
   c->bk_level2 = true;
   return KC_OK;
 }
@@ -1343,10 +1571,18 @@ static int bk_finalize(kc_ctx *c) {
       // every block ever taken must lie inside the arrays, or entries were dropped: run again with enough room
       if (c->h_cb[CB_OUT_RESERVED] <= c->out_cap) break;
       cap = c->h_ctrs[CTR_OUT] + slack;
+      if (attempt == 2) {
+        snprintf(g_last_error, sizeof(g_last_error), "result arrays still too small after three passes (%llu entries)", (unsigned long long)cap);
+        return KC_ERR_CAPACITY;
+      }
       continue;
     }
     if (c->h_ctrs[CTR_OUT] <= c->out_cap) break;
     cap = c->h_ctrs[CTR_OUT];  // the pass only counted past the end: run it again with exactly enough room
+    if (attempt == 2) {
+      snprintf(g_last_error, sizeof(g_last_error), "result arrays still too small after three passes (%llu entries)", (unsigned long long)cap);
+      return KC_ERR_CAPACITY;
+    }
   }
   rc = bk_move_flagged(c);
   if (rc) return rc;

@@ -87,6 +87,11 @@ struct BucketBufs {
 enum {  // counters of this path, one u64 each
   CB_OVF1 = 0, CB_OVF2, CB_FATAL, CB_FLAGGED_RECS, CB_DUMP, CB_ENTRIES, CB_OUT_RESERVED, CB_COUNT = 16
 };
+// bits of cb[CB_FATAL]: records were lost, the pass that set one cannot be used
+enum { FATAL_OVF1 = 1,    // level-1 overflow list full (the host bounds every launch by the list's free room: cannot happen)
+       FATAL_ARENA2 = 2,  // level-2 arena smaller than the buffered records (cannot happen either)
+       FATAL_OVF2 = 4 };  // level-2 overflow list full: the host makes it as large as cb[CB_OVF2] says and runs level 2 again
+
 
 // Four independent fields of the 64-bit k-mer hash: bits 0-15 pick the level-1 bucket, 16-31 the level-2 bucket
 // (each by multiply-shift, so the fan-outs need not be powers of two; 65536 / P >= 64 values per bucket keeps the
@@ -408,7 +413,7 @@ __device__ __forceinline__ void l1_overflow(const Geom &gm, const BucketBufs &bb
 #pragma unroll
     for (int w = 0; w < NL; w++) bb.ovf1[o * NL + w] = (CP && w == 0) ? cp_unmix_rec(r[w], gm) : r[w];
   } else {
-    cb[CB_FATAL] = 1;
+    atomicOr((unsigned long long *)&cb[CB_FATAL], (unsigned long long)FATAL_OVF1);
   }
 }
 
@@ -822,7 +827,7 @@ __global__ __launch_bounds__(WGB) void kc_bucket_prefix_kernel(Geom gm, BucketBu
   if (b < gm.P1) bb.base2[b] = e;
   if (b == 0) {
     bb.base2[gm.P1] = S.total;
-    if (S.total > gm.A2) cb[CB_FATAL] = 2;  // cannot happen while the host keeps the buffered records within its capacity
+    if (S.total > gm.A2) atomicOr((unsigned long long *)&cb[CB_FATAL], (unsigned long long)FATAL_ARENA2);  // the host keeps the buffered records within its capacity
   }
 }
 
@@ -955,7 +960,7 @@ __global__ __launch_bounds__(WGB) void kc_l2_split_kernel(Geom gm, BucketBufs bb
 #pragma unroll
               for (int w = 0; w < NL; w++) bb.ovf2[o * NL + w] = (CP && w == 0) ? cp_unmix_rec(r[w], gm) : r[w];
             } else {
-              cb[CB_FATAL] = 1;
+              atomicOr((unsigned long long *)&cb[CB_FATAL], (unsigned long long)FATAL_OVF2);
             }
           },
           [&](size_t i, const uint64_t (&r)[NL]) {
@@ -990,7 +995,28 @@ __global__ void kc_ovf1_to_regions_kernel(Geom gm, BucketBufs bb, uint64_t n, ui
   if (o < bb.ovf2_cap) {
     for (int w = 0; w < NL; w++) bb.ovf2[o * NL + w] = r[w];
   } else {
-    cb[CB_FATAL] = 1;
+    atomicOr((unsigned long long *)&cb[CB_FATAL], (unsigned long long)FATAL_OVF2);
+  }
+}
+
+// The level-1 overflow list is nearly full while reads are still coming in: its records go to the global table now (their
+// regions are flagged, so that the table gets the regions' other records too when the stage is finalized) and the list
+// starts again empty.
+template <int NL, bool CP>
+__global__ __launch_bounds__(TPB) void kc_ovf1_drain_kernel(Geom gm, BucketBufs bb, uint64_t n, Table t, uint64_t *ctrs) {
+  for (uint64_t i = (uint64_t)blockIdx.x * TPB + threadIdx.x; i < n; i += (uint64_t)gridDim.x * TPB) {
+    uint64_t r[NL];
+    for (int w = 0; w < NL; w++) r[w] = bb.ovf1[i * NL + w];
+    size_t reg;
+    if (CP) {
+      const uint64_t m = cp_mix_rec(r[0], gm);
+      reg = (size_t)cp_b1(m, gm) * gm.P2 + cp_b2(m, gm);
+    } else {
+      const uint64_t h = rec_hash<NL>(r);
+      reg = (size_t)hash_b1(h, gm) * gm.P2 + hash_b2(h, gm);
+    }
+    bb.flag[reg] = 1;
+    table_insert<NL>(t, r, ctrs);
   }
 }
 

@@ -126,10 +126,15 @@ __device__ __forceinline__ void table_insert(const Table &t, const uint64_t (&re
   } else {
     // the last word is lock + publish: EMPTY -> BUSY -> value.  Every read of shared key words is a
     // device-scope RMW so that it is served by the coherent memory side, never by another XCD's L2.
-    for (;;) {
+    // Predicated form (a flag per lane, no divergent exit): the lane that claimed a slot publishes inside the very
+    // trip in which another lane of its wave may have seen BUSY, whatever the compiler makes of the control flow.
+    bool done = false;
+    do {
       unsigned long long *ks = (unsigned long long *)(t.keys + slot * NL);
-      uint64_t old = atomicCAS(&ks[NL - 1], (unsigned long long)KEY_EMPTY, (unsigned long long)KEY_BUSY);
-      if (old == KEY_EMPTY) {
+      unsigned long long old = KEY_BUSY;
+      if (!done) old = atomicCAS(&ks[NL - 1], (unsigned long long)KEY_EMPTY, (unsigned long long)KEY_BUSY);
+      const bool won = !done && old == KEY_EMPTY;
+      if (won) {
 #pragma unroll
         for (int j = 0; j < NL - 1; j++)
           __hip_atomic_store(&ks[j], (unsigned long long)key[j], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
@@ -137,17 +142,16 @@ __device__ __forceinline__ void table_insert(const Table &t, const uint64_t (&re
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
         atomicExch(&ks[NL - 1], (unsigned long long)key[NL - 1]);
         is_new = true;
-        break;
       }
-      if (old == KEY_BUSY) continue;  // owner publishes within this same loop trip of its wave
-      if (old == key[NL - 1]) {
-        bool same = true;
+      bool same = !done && old == key[NL - 1];
+      if (same) {
 #pragma unroll
         for (int j = 0; j < NL - 1; j++) same &= (atomicOr(&ks[j], 0ULL) == key[j]);
-        if (same) break;
       }
-      slot = (slot + 1) & t.mask;
-    }
+      const bool busy = !done && old == KEY_BUSY;  // its owner publishes within this same trip of its own wave: look again
+      if (!done && !won && !same && !busy) slot = (slot + 1) & t.mask;
+      done = done || won || same;
+    } while (__any(!done));
   }
   uint32_t *v = t.vals + slot * 9;
   sat_inc(v);                              // S6 count

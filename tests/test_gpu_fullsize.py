@@ -1,10 +1,14 @@
-"""Parity at sizes the oracle cannot reach in seconds, through size-independent properties (BASELINE config 2 is
-50 M reads; the default here is 10 M to keep the suite short, KC_FULLSIZE_READS=50000000 runs the real size):
+"""Parity at sizes the oracle cannot reach in seconds, through size-independent properties.  BASELINE config 2 is
+50 M reads at k=21 and that is what runs by default (KC_FULLSIZE_READS overrides it); the two- and three-word
+paths of configs 4 and 5 (k=51, k=77) run at KC_FULLSIZE_READS_LONG reads (10 M by default):
   * every k-mer occurrence with two neighbours is inserted exactly once (count known in closed form);
   * the bucketed path and the global-table path -- two unrelated implementations -- agree on the result set
     (checksum of checksums), on the number of distinct k-mers and on the sum of counts;
   * a second run over the same input gives the same checksum (idempotence);
-  * a prefix of the same read stream that the oracle can still finish is bit-exact against it."""
+  * a prefix of the same read stream that the oracle can still finish is bit-exact against it.
+And skew at scale: heavy hitters (a poly-A read in every hundred, one k-mer planted in every read) with the default
+geometry must neither fail nor drop anything (reference drop semantics being avoided: kcount_cpu.cpp:232-268,
+gpu_hash_table.cpp:392-395)."""
 import os
 
 import numpy as np
@@ -15,39 +19,42 @@ from oracle import cpu_oracle as O
 
 pytestmark = pytest.mark.gpu
 
-NREADS = int(os.environ.get("KC_FULLSIZE_READS", "10000000"))
+NREADS = int(os.environ.get("KC_FULLSIZE_READS", "50000000"))
+NREADS_LONG = int(os.environ.get("KC_FULLSIZE_READS_LONG", "10000000"))
 L = 150
 
 
 def checksum(kc):
     kk, cc, ll, rr = kc.results()
-    h = (kk[:, 0] * np.uint64(0x9E3779B97F4A7C15)) ^ (cc.astype(np.uint64) << np.uint64(8)) ^ ll.astype(np.uint64) \
-        ^ (rr.astype(np.uint64) << np.uint64(4))
-    return int(np.bitwise_xor.reduce(h)), int(h.sum(dtype=np.uint64)), len(cc)
+    h = cc.astype(np.uint64) << np.uint64(8)
+    for w in range(kk.shape[1]):
+        h ^= kk[:, w] * np.uint64(0x9E3779B97F4A7C15 + 2 * w)
+    h ^= ll.astype(np.uint64) ^ (rr.astype(np.uint64) << np.uint64(4))
+    return int(np.bitwise_xor.reduce(h)) if len(cc) else 0, int(h.sum(dtype=np.uint64)), len(cc)
 
 
-def test_full_size_properties():
+@pytest.mark.parametrize("k,nreads", [(21, NREADS), (51, NREADS_LONG), (77, NREADS_LONG)])
+def test_full_size_properties(k, nreads):
     import torch
-    k = 21
     p = pkg.synth_params()
-    db = torch.empty(NREADS * L, dtype=torch.uint8, device="cuda")
-    dq = torch.empty(NREADS * L, dtype=torch.uint8, device="cuda")
-    do = torch.empty(NREADS + 1, dtype=torch.int64, device="cuda")
-    est = int(64 * 4_000_000 + NREADS * L * 0.005 * k * 1.05) + (1 << 20)
+    db = torch.empty(nreads * L, dtype=torch.uint8, device="cuda")
+    dq = torch.empty(nreads * L, dtype=torch.uint8, device="cuda")
+    do = torch.empty(nreads + 1, dtype=torch.int64, device="cuda")
+    est = int(64 * 4_000_000 + nreads * L * 0.005 * k * 1.05) + (1 << 20)
     sums = {}
     for name, tuning in (("bucketed", None), ("table", dict(mode=1))):
-        with pkg.KmerCounter(k, max_elems=est, max_kmers_buffered=int(NREADS * (L - k - 1) * 1.02) + (1 << 20), tuning=tuning) as kc:
+        with pkg.KmerCounter(k, max_elems=est, max_kmers_buffered=int(nreads * (L - k - 1) * 1.02) + (1 << 20), tuning=tuning) as kc:
             if name == "bucketed":
-                kc.synth_reads_device(db, dq, do, NREADS, params=p)
-            kc.submit_reads(db, dq, do, nreads=NREADS)
+                kc.synth_reads_device(db, dq, do, nreads, params=p)
+            kc.submit_reads(db, dq, do, nreads=nreads)
             c1 = checksum(kc)
             st = kc.stats()
-            assert st["kmers_inserted"] == NREADS * (L - k - 1)
-            assert st["raw_kmers"] == NREADS * (L - k + 1)
+            assert st["kmers_inserted"] == nreads * (L - k - 1)
+            assert st["raw_kmers"] == nreads * (L - k + 1)
             assert st["num_dropped"] == 0 and st["total_kmers"] == c1[2]
             if name == "bucketed":
                 kc.reset()
-                kc.submit_reads(db, dq, do, nreads=NREADS)
+                kc.submit_reads(db, dq, do, nreads=nreads)
                 assert checksum(kc) == c1  # idempotent
             sums[name] = (c1, st["num_unique"], st["sum_counts"], st["num_purged"])
     assert sums["bucketed"] == sums["table"]
@@ -61,3 +68,77 @@ def test_full_size_properties():
     got, _ = pkg.analyze_kmers(k, 33, db[:n_small * L], dq[:n_small * L], do[:n_small + 1])
     for g, w in zip(got, want):
         assert g.shape == w.shape and (g == w).all()
+
+
+def skewed_reads(nreads, rl, k, genome_len, seed):
+    """Reads from a random genome, both strands, 0.5 % substitutions; a k-mer (with both neighbours) planted in every
+    read, every hundredth read all A.  Built on the GPU (torch is plumbing here); returns device tensors."""
+    import torch
+    g = torch.Generator(device="cuda")
+    g.manual_seed(seed)
+    acgt = torch.tensor([65, 67, 71, 84], dtype=torch.uint8, device="cuda")
+    genome = torch.randint(0, 4, (genome_len,), generator=g, device="cuda", dtype=torch.uint8)
+    motif = torch.randint(0, 4, (k + 2,), generator=g, device="cuda", dtype=torch.uint8)
+    out = torch.empty(nreads * rl, dtype=torch.uint8, device="cuda")
+    step = 500_000
+    ar = torch.arange(rl, device="cuda")
+    for r0 in range(0, nreads, step):
+        n = min(step, nreads - r0)
+        starts = torch.randint(0, genome_len - rl, (n,), generator=g, device="cuda")
+        codes = genome[starts[:, None] + ar[None, :]]
+        rev = torch.rand(n, generator=g, device="cuda") < 0.5
+        codes = torch.where(rev[:, None], 3 - codes.flip(1), codes)
+        err = torch.rand((n, rl), generator=g, device="cuda") < 0.005
+        codes = torch.where(err, (codes + 1 + torch.randint(0, 3, (n, rl), generator=g, device="cuda", dtype=torch.uint8)) & 3, codes)
+        codes[:, 30:30 + k + 2] = motif[None, :]
+        codes[(torch.arange(n, device="cuda") + r0) % 100 == 0] = 0
+        out[r0 * rl:(r0 + n) * rl] = acgt[codes.long()].reshape(-1)
+    quals = torch.full((nreads * rl,), ord("I"), dtype=torch.uint8, device="cuda")
+    offs = torch.arange(nreads + 1, dtype=torch.int64, device="cuda") * rl
+    return out, quals, offs, motif
+
+
+def pack(codes, k):
+    """2-bit codes of one k-mer -> canonical packed words (kmer.cpp layout), through the oracle's own primitives"""
+    s = "".join("ACGT"[int(c)] for c in codes)
+    w = O.pack_kmer(s, k)
+    r = O.revcomp(w, k)
+    return r if tuple(r) < tuple(w) else w
+
+
+def test_heavy_hitters_at_scale_with_the_default_geometry():
+    k, rl, nreads = 21, 100, int(os.environ.get("KC_SKEW_READS", "5000000"))
+    b, q, offs, motif = skewed_reads(nreads, rl, k, 3_000_000, seed=7)
+    sums = {}
+    for name, tuning in (("bucketed", None), ("table", dict(mode=1))):
+        # default geometry and default overflow lists; the buffer holds the input, nothing else is tuned
+        with pkg.KmerCounter(k, max_kmers_buffered=nreads * (rl - k - 1) + (1 << 20), tuning=tuning) as kc:
+            kc.submit_reads(b, q, offs, nreads=nreads)
+            c = checksum(kc)
+            st = kc.stats()
+            assert st["num_dropped"] == 0 and st["kmers_inserted"] == nreads * (rl - k - 1)
+            sums[name] = (c, st["num_unique"], st["sum_counts"], st["num_purged"])
+            # the two heavy hitters are there, saturated (S6)
+            heavy = np.stack([pack(motif[1:k + 1].cpu().numpy(), k), pack(np.zeros(k, dtype=np.uint8), k)])
+            cnt, _, _ = kc.lookup(heavy)
+            assert list(cnt) == [65535, 65535]
+    assert sums["bucketed"] == sums["table"]
+
+
+def test_heavy_hitters_match_the_oracle():
+    k, rl, nreads = 21, 60, 300_000
+    b, q, offs, _ = skewed_reads(nreads, rl, k, 200_000, seed=11)
+    hb, hq, ho = b.cpu().numpy(), q.cpu().numpy(), offs.cpu().numpy().astype(np.uint64)
+    o = O.Oracle(k, nranks=8, nthreads=8)
+    o.add_reads(hb, hq, ho)
+    want = o.finalize()
+    ost = o.stats()
+    o.close()
+    # a buffer a tenth of the default: the planted k-mer's region and the poly-A one outgrow their chains many times over
+    with pkg.KmerCounter(k, max_kmers_buffered=nreads * (rl - k - 1) + 4096) as kc:
+        kc.submit_reads(b, q, offs, nreads=nreads)
+        got = kc.sorted_results()
+        st = kc.stats()
+    for g, w in zip(got, want):
+        assert g.shape == w.shape and (g == w).all()
+    assert st["num_unique"] == ost["unique"] and st["num_dropped"] == 0

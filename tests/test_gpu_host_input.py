@@ -1,0 +1,83 @@
+"""Host-resident reads through the overlapped staging of kc_submit_reads / kc_submit_packed_reads (two device slots,
+two pinned host slots, copies on their own stream): many blocks, pageable and pinned sources, against the oracle.
+Role in the reference: the block loop of src/kcount/kcount_gpu.cpp:110-165."""
+import os
+
+import numpy as np
+import pytest
+
+import mhm2_kmer_analysis_v2_amd as pkg
+from helpers import random_reads
+from oracle import cpu_oracle as O
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.fixture
+def small_blocks(monkeypatch):
+    monkeypatch.setenv("KC_HOST_BLOCK", str(1 << 20))  # 1 MiB of bases per block: a few MB of reads make many blocks
+
+
+def _input(k, n=75000, seed=5):
+    rng = np.random.default_rng(seed)
+    reads, quals = random_reads(rng, n, min_len=k - 3, max_len=k + 130, genome_len=40000, err=0.01)
+    b, q, offs = O.reads_to_arrays(reads, quals)
+    assert len(b) > 5 * (1 << 20)  # at least five blocks
+    o = O.Oracle(k, nranks=8, nthreads=8)
+    o.add_reads(b, q, offs)
+    want = o.finalize()
+    st = o.stats()
+    o.close()
+    return b, q, offs, want, st
+
+
+@pytest.mark.parametrize("k", [21, 51])
+@pytest.mark.parametrize("source", ["pageable", "pinned"])
+def test_host_reads_in_many_blocks(small_blocks, k, source):
+    import torch
+    b, q, offs, want, wst = _input(k)
+    keep = None
+    if source == "pinned":
+        keep = (torch.from_numpy(b).pin_memory(), torch.from_numpy(q).pin_memory())
+        b, q = keep[0].numpy(), keep[1].numpy()
+    with pkg.KmerCounter(k) as kc:
+        kc.submit_reads(b, q, offs)
+        got = kc.sorted_results()
+        st = kc.stats()
+    for g, w in zip(got, want):
+        assert g.shape == w.shape and (g == w).all()
+    assert st["num_reads"] == wst["reads"] and st["raw_kmers"] == wst["raw_kmers"] and st["num_bases"] == len(b)
+
+
+def test_host_packed_reads_in_many_blocks(small_blocks):
+    k = 21
+    b, q, offs, want, _ = _input(k, seed=6)
+    # the read cache's byte: base code 0-4 (ACGTN) | min(quality - offset, 31) << 3 (src/packed_reads.cpp:99-126)
+    code = np.full(256, 4, dtype=np.uint8)
+    for i, ch in enumerate("ACGT"):
+        code[ord(ch)] = i
+        code[ord(ch.lower())] = i
+    packed = code[b] | (np.minimum(q.astype(np.int32) - 33, 31).astype(np.uint8) << 3)
+    with pkg.KmerCounter(k) as kc:
+        kc.submit_packed_reads(packed, offs)
+        got = kc.sorted_results()
+    for g, w in zip(got, want):
+        assert g.shape == w.shape and (g == w).all()
+
+
+def test_blocks_of_one_long_read(small_blocks):
+    """a read longer than a block gets a block of its own"""
+    k = 33
+    rng = np.random.default_rng(8)
+    long_read = "".join(rng.choice(list("ACGT"), size=(3 << 20) + 17))
+    reads = ["ACGT" * 30, long_read, "TTGACCA" * 20, long_read[1000:2000]]
+    b, q, offs = O.reads_to_arrays(reads)
+    o = O.Oracle(k, nranks=2, nthreads=2)
+    o.add_reads(b, q, offs)
+    want = o.finalize()
+    o.close()
+    with pkg.KmerCounter(k) as kc:
+        kc.submit_reads(b, q, offs)
+        got = kc.sorted_results()
+    for g, w in zip(got, want):
+        assert g.shape == w.shape and (g == w).all()

@@ -22,6 +22,22 @@ sys.path.insert(0, ROOT)
 
 ALG_BYTES_PER_KMER = {1: 34.0, 2: 46.0, 3: 58.0, 4: 70.0}  # SURVEY.md section 8d contract constants, by num_longs
 HBM_PEAK_GBPS = 8000.0  # MI355X_MICROARCH.md: 8.0 TB/s spec
+PROFILE = "profiles/r02_pmc_50Mreads.json"  # rocprofv3 PMC passes of this same command (scripts/pmc_profile.sh)
+
+
+def own_alg_bytes(kernel, nl, k, read_len, results_per_raw):
+    """Algorithmic HBM bytes per raw k-mer of ONE kernel of this design: what that kernel must
+    read and write at least, so that its fraction of the roofline cannot exceed 1.  Compact records (k <= 23): level 1
+    writes 8-byte records, level 2 turns them into 4-byte ones."""
+    rec1 = 8.0 * nl
+    rec2 = 4.0 if (nl == 1 and k <= 23) else 8.0 * nl
+    if "l1_reads" in kernel:
+        return 2.0 * read_len / (read_len - k + 1) + rec1   # bases + qualities in, level-1 records out
+    if "l2_split" in kernel:
+        return rec1 + rec2
+    if "count_kernel" in kernel:
+        return rec2 + results_per_raw * (8.0 * nl + 4.0)    # region records in, dense results out
+    return None
 
 
 def parse_args():
@@ -32,7 +48,8 @@ def parse_args():
     ap.add_argument("--reads", type=int, default=50_000_000, help="reads per GPU (150 bp each)")
     ap.add_argument("--k", type=int, default=21)
     ap.add_argument("--block-reads", type=int, default=8_000_000, help="N>1: reads per exchange block")
-    ap.add_argument("--cpu-sample-reads", type=int, default=1_000_000, help="reads timed through the CPU oracle (0 = skip)")
+    ap.add_argument("--cpu-sample-reads", type=int, default=4_000_000, help="reads timed through the CPU oracle (0 = skip)")
+    ap.add_argument("--no-end-to-end", action="store_true", help="skip the host-resident (PCIe-inclusive) leg at N=1")
     ap.add_argument("--check", action="store_true", help="size-independent result checks after the timed region")
     ap.add_argument("--table-path", action="store_true", help="A/B: force the global-table insert path instead of the bucketed one")
     ap.add_argument("--force-sharded", action="store_true", help="run the N>1 code path (bin by owner, exchange, insert records) even at N=1")
@@ -40,21 +57,21 @@ def parse_args():
     return ap.parse_args()
 
 
-def pmc_traffic(kernel_name, nreads, k, tuned):
-    """HBM bytes per launch of `kernel_name` from the committed rocprofv3 PMC passes of this same workload
-    (scripts/pmc_profile.sh: FETCH_SIZE and WRITE_SIZE in separate passes; FETCH_SIZE doubled as
-    MI355X_MICROARCH.md prescribes for wide coalesced reads on gfx950).  None when no profile matches."""
+def pmc_traffic(nreads, k, tuned):
+    """HBM bytes per STEP of every kernel from the committed rocprofv3 PMC passes of this same workload
+    (scripts/pmc_profile.sh: FETCH_SIZE and WRITE_SIZE in separate passes; FETCH_SIZE doubled as MI355X_MICROARCH.md
+    prescribes for wide coalesced reads on gfx950).  {} when no profile matches the workload."""
     if nreads != 50_000_000 or k != 21 or tuned:
-        return None, None
-    path = os.path.join(ROOT, "profiles", "r01_bucketed_final_pmc_50Mreads.json")
+        return {}, None
     try:
-        prof = json.load(open(path))
+        prof = json.load(open(os.path.join(ROOT, PROFILE)))
     except Exception:
-        return None, None
+        return {}, None
+    out = {}
     for name, ctr in prof.items():
-        if kernel_name in name and "FETCH_SIZE" in ctr and "WRITE_SIZE" in ctr:
-            return (2.0 * ctr["FETCH_SIZE"] + ctr["WRITE_SIZE"]) * 1024.0, os.path.relpath(path, ROOT)
-    return None, None
+        if "FETCH_SIZE" in ctr and "WRITE_SIZE" in ctr:
+            out[name] = (2.0 * ctr["FETCH_SIZE"] + ctr["WRITE_SIZE"]) * 1024.0
+    return out, PROFILE
 
 
 def usable_cores():
@@ -69,27 +86,85 @@ def usable_cores():
     return n
 
 
-def cpu_baseline(k, nreads, params):
-    """The oracle (a port of the reference CPU kcount, oracle/kcount_oracle.c) on this host's cores,
-    on a bounded sample of the same read stream.  Reported beside the GPU number; never the target."""
+def cpu_model():
+    try:
+        for line in open("/proc/cpuinfo"):
+            if line.startswith("model name"):
+                return line.split(":", 1)[1].strip()
+    except Exception:
+        pass
+    return "unknown"
+
+
+def cpu_baseline(k, nreads, full_reads, params):
+    """The oracle (a port of the reference CPU kcount, oracle/kcount_oracle.c: minimizer-hash partition into one
+    emulated rank per core, ASCII supermers, receiver re-derives the k-mers, MurmurHash3 + prime-capacity linear-probe
+    table with separate key and value arrays, two-scan finalize per rank, no sort) on this host's cores, on a bounded
+    sample of the same read stream at the SAME depth as the GPU run: the genomes are scaled with the number of reads,
+    and every rank's table is sized for the sample's distinct k-mers, so nothing rehashes while timed (`rehashes`).
+    Reported beside the GPU number; never the target."""
     import mhm2_kmer_analysis_v2_amd as pkg
     from oracle import cpu_oracle as O
     cores = usable_cores()
-    b, q, offs = pkg.synth_reads_host(nreads, params=params)
-    raw = nreads * (params.read_len - k + 1)  # fixed-length reads
-    # table sized by the reference's rule so that it never grows inside the timed region:
-    # (adjusted + errors) / 0.66 with sequencing_depth 4, BASE_ERROR_RATE 0.005 (kmer_dht.cpp:126-131)
-    per_rank = int((raw / 4 + raw * (1 - (1 - 0.005) ** k)) / 0.66 / cores) + 1024
+    scale = nreads / float(full_reads)
+    sp = pkg.synth_params(min_genome_len=max(1000, int(params.min_genome_len * scale)),
+                          max_genome_len=max(2000, int(params.max_genome_len * scale)))
+    b, q, offs = pkg.synth_reads_host(nreads, params=sp)
+    L = sp.read_len
+    raw = nreads * (L - k + 1)  # fixed-length reads
+    distinct = sp.num_genomes * (sp.min_genome_len + sp.max_genome_len) / 2 + nreads * L * sp.sub_error_rate * k * 1.05
+    per_rank = int(distinct / 0.5 / cores * 1.6) + 1024  # load <= 0.5 with room for the minimizer partition's imbalance
     o = O.Oracle(k, nranks=cores, nthreads=cores, capacity_per_rank=per_rank)
     t0 = time.perf_counter()
     o.add_reads(b, q, offs, block_reads=250_000)
-    o.finalize()
+    o.finalize_unsorted()
     dt = time.perf_counter() - t0
     st = o.stats()
     o.close()
-    return {"value": st["raw_kmers"] / dt, "unit": "k-mers/s", "cores": cores, "kind": "port",
-            "sample": "%d reads x %d bp of the same synthetic stream, k=%d, %d emulated ranks, %.1f s" % (
-                nreads, params.read_len, k, cores, dt)}
+    return {"value": st["raw_kmers"] / dt, "unit": "k-mers/s", "cores": cores, "kind": "port", "cpu": cpu_model(),
+            "rehashes": st["rehashes"],
+            "sample": "%d reads x %d bp of the same synthetic stream with genomes scaled to the same depth as the GPU run, k=%d, "
+                      "%d emulated ranks on %d threads, %.1f s" % (nreads, L, k, cores, cores, dt)}
+
+
+def end_to_end(kc, k, L, d_bases, d_quals, d_offs, nreads):
+    """The stage with the reads starting in HOST memory (pinned), H2D included: what a host caller of kc_submit_reads /
+    kc_submit_packed_reads gets.  ASCII bases + qualities (2 B/base) and the read cache's packed bytes (1 B/base,
+    src/packed_reads.cpp:99-126).  PCIe-bound by a wide margin: reported beside `value`, never as it."""
+    import numpy as np
+    import torch
+    raw = nreads * (L - k + 1)
+    hb = d_bases.cpu().pin_memory()
+    hq = d_quals.cpu().pin_memory()
+    ho = d_offs.cpu().numpy().astype(np.uint64)
+    out = {}
+    # the packed bytes: base code 0-4 (ACGTN) | min(quality - 33, 31) << 3, made on the GPU piece by piece
+    code = torch.full((256,), 4, dtype=torch.uint8, device=d_bases.device)
+    for i, ch in enumerate(b"ACGT"):
+        code[ch] = i
+    d_packed = torch.empty_like(d_bases)
+    step = 1 << 28
+    for o in range(0, d_bases.numel(), step):
+        bb = d_bases[o:o + step]
+        d_packed[o:o + step] = code[bb.long()] | ((d_quals[o:o + step].to(torch.int16) - 33).clamp(max=31).to(torch.uint8) << 3)
+    hp = d_packed.cpu().pin_memory()
+    del d_packed
+    for name, fn, nbytes in (("ascii", lambda: kc.submit_reads(hb.numpy(), hq.numpy(), ho), 2 * nreads * L),
+                             ("packed", lambda: kc.submit_packed_reads(hp.numpy(), ho), nreads * L)):
+        best = None
+        for _ in range(2):
+            kc.reset()
+            torch.cuda.synchronize()
+            t0 = time.perf_counter()
+            fn()
+            kc.finalize()
+            torch.cuda.synchronize()
+            dt = time.perf_counter() - t0
+            best = dt if best is None else min(best, dt)
+        out[name] = {"ms_per_step": best * 1e3, "value": raw / best, "unit": "k-mers/s", "input_bytes": nbytes,
+                     "input_GBps_over_pcie": nbytes / best / 1e9}
+    out["note"] = "host-resident pinned input, H2D inside the timed region, results left in HBM; PCIe Gen5 x16 is 63 GB/s (spec)"
+    return out
 
 
 def main():
@@ -215,21 +290,35 @@ def main():
     value = world * raw_per_rank * a.steps / dt
     out = None
     if rank == 0:
-        # dominant kernel by device time; HIP events recorded on the launch stream inside the library
-        dom = max(ktimes.items(), key=lambda kv: kv[1][1]) if ktimes else None
-        roof = None
-        if dom:
-            name, (launches, total_ms) = dom
-            avg_ms = total_ms / launches
-            # algorithmic bytes per launch = contract bytes per raw k-mer x raw k-mers one launch processes
-            raw_per_launch = raw_per_rank * a.steps / launches
-            achieved = ALG_BYTES_PER_KMER[nl] * raw_per_launch / (avg_ms * 1e-3) / 1e9
-            traffic, traffic_src = pmc_traffic(name, nreads, k, bool(a.tune) or a.table_path or sharded_path)
-            roof = {"bound": "hbm", "kernel": name, "achieved": achieved, "peak": HBM_PEAK_GBPS, "unit": "GB/s",
-                    "frac": achieved / HBM_PEAK_GBPS, "traffic": traffic, "traffic_source": traffic_src,
-                    "launches": launches, "avg_launch_ms": avg_ms,
-                    "alg_bytes_per_kmer": ALG_BYTES_PER_KMER[nl], "kmers_per_launch": raw_per_launch,
-                    "kernels_ms": {n: round(v[1] / a.steps, 3) for n, v in ktimes.items()}}
+        # Roofline of the STAGE: the contract's algorithmic bytes per raw k-mer x the raw k-mers one rank
+        # puts through a step, over the step's wall time as timed above -- all kernels, gaps and host round trips in.
+        # `kernels`: every kernel with ITS OWN algorithmic bytes (own_alg_bytes) over its own device time (HIP events
+        # recorded on the launch stream inside the library), and its PMC traffic per step where a profile of this
+        # workload is committed; the dominant one is named in `kernel`.
+        tuned = bool(a.tune) or a.table_path or sharded_path
+        traffic, traffic_src = pmc_traffic(nreads, k, tuned)
+        step_s = dt / a.steps
+        achieved = ALG_BYTES_PER_KMER[nl] * raw_per_rank / step_s / 1e9
+        results_per_raw = st["total_kmers"] / float(raw_per_rank) if raw_per_rank else 0.0
+        kernels = []
+        for name, (launches, total_ms) in sorted(ktimes.items(), key=lambda kv: -kv[1][1]):
+            ms_step = total_ms / a.steps
+            own = own_alg_bytes(name, nl, k, L, results_per_raw)
+            ent = {"name": name, "launches_per_step": launches / a.steps, "avg_launch_ms": total_ms / launches, "ms_per_step": ms_step}
+            if own is not None and not sharded_path and not a.table_path:
+                gbps = own * raw_per_rank / (ms_step * 1e-3) / 1e9
+                ent.update({"alg_bytes_per_kmer": round(own, 3), "achieved_GBps": gbps, "frac": gbps / HBM_PEAK_GBPS})
+            tr = next((v for n, v in traffic.items() if name in n), None)
+            if tr is not None:
+                ent.update({"traffic_bytes_per_step": tr, "traffic_GBps": tr / (ms_step * 1e-3) / 1e9})
+            kernels.append(ent)
+        dom = kernels[0] if kernels else None
+        roof = {"bound": "hbm", "scope": "stage (all kernels of a step, wall time)", "achieved": achieved, "peak": HBM_PEAK_GBPS,
+                "unit": "GB/s", "frac": achieved / HBM_PEAK_GBPS, "alg_bytes_per_kmer": ALG_BYTES_PER_KMER[nl],
+                "kmers_per_step": raw_per_rank, "kernel": dom["name"] if dom else None,
+                "traffic": sum(traffic.values()) if traffic else None, "traffic_unit": "bytes per step, all kernels",
+                "traffic_source": traffic_src, "kernels": kernels,
+                "kernels_ms": {n: round(v[1] / a.steps, 3) for n, v in ktimes.items()}}
         out = {
             "metric": "k-mers/sec (kcount stage) at k=%d" % k, "value": value, "unit": "k-mers/s", "n_gpus": world,
             "steps": a.steps, "warmup": a.warmup, "ms_per_step": dt / a.steps * 1e3, "higher_is_better": True,
@@ -243,11 +332,13 @@ def main():
         }
         if checks is not None:
             out["checks"] = checks
-    # CPU baseline: rank 0 at N=1 only, bounded sample
+    # host-resident input (PCIe-inclusive) and the CPU baseline: rank 0 at N=1 only, outside the timed region
+    if rank == 0 and world == 1 and not sharded_path and not a.no_end_to_end:
+        out["end_to_end"] = end_to_end(kc, k, L, d_bases, d_quals, d_offs, nreads)
     if rank == 0 and world == 1 and a.cpu_sample_reads > 0:
         kc.close()
         del d_bases, d_quals, d_offs
-        out["cpu_baseline"] = cpu_baseline(k, min(a.cpu_sample_reads, nreads), params)
+        out["cpu_baseline"] = cpu_baseline(k, min(a.cpu_sample_reads, nreads), nreads, params)
     elif rank == 0:
         out["cpu_baseline"] = None
     if rank == 0:

@@ -64,6 +64,8 @@ def lib():
         L.orc_insert_supermer.argtypes = [C.c_void_p, C.c_int, C.c_char_p, C.c_int]
         L.orc_finalize.restype = C.c_int
         L.orc_finalize.argtypes = [C.c_void_p]
+        L.orc_finalize_ex.restype = C.c_int
+        L.orc_finalize_ex.argtypes = [C.c_void_p, C.c_int]
         L.orc_num_results.restype = C.c_uint64
         L.orc_num_results.argtypes = [C.c_void_p]
         L.orc_get_results.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]
@@ -134,7 +136,7 @@ def kmer_to_string(words, k):
 
 
 STAT_NAMES = ("reads", "raw_kmers", "supermers", "kmers_inserted", "unique", "purged", "total_kmers",
-              "sum_counts", "dropped", "nranks", "nthreads")
+              "sum_counts", "dropped", "nranks", "nthreads", "rehashes")
 
 
 class Oracle:
@@ -172,6 +174,13 @@ class Oracle:
         rc = lib().orc_insert_supermer(self._h, target, b, len(b))
         if rc:
             raise RuntimeError("orc_insert_supermer failed: %d" % rc)
+
+    def finalize_unsorted(self):
+        """Vote, purge and collect like the reference does (per rank, in parallel, no sort); returns the number of
+        results.  What the CPU baseline times; the tests use finalize(), which also sorts by key."""
+        if lib().orc_finalize_ex(self._h, 0):
+            raise MemoryError
+        return lib().orc_num_results(self._h)
 
     def finalize(self):
         if lib().orc_finalize(self._h):

@@ -294,6 +294,7 @@ typedef struct {
   uint64_t num_elems;
   uint64_t num_dropped;
   uint64_t sum_probe, max_probe;
+  uint64_t num_grows; /* rehashes so far: a timed run sized by the reference's rule should show 0 */
   uint64_t *keys; /* capacity * nl, 0xFF filled */
   orc_vals *vals;
 } orc_table;
@@ -364,6 +365,7 @@ static int table_grow(orc_table *t, int nl) {
     nt.num_elems++;
   }
   nt.num_dropped = t->num_dropped;
+  nt.num_grows = t->num_grows + 1;
   table_free(t);
   *t = nt;
   return 0;
@@ -628,50 +630,94 @@ static int rec_cmp(const void *a, const void *b) {
   return 0;
 }
 
-/* insert_into_local_hashtable (kcount_cpu.cpp:523-601): vote, purge, collect.
- * Results of all ranks are concatenated and sorted by key (S9). */
-int orc_finalize(orc_ctx *c) {
+/* insert_into_local_hashtable (kcount_cpu.cpp:523-601): vote, purge, collect.  Like the reference every rank works
+ * on its own table (here: one OpenMP thread per rank at a time) in two scans: count the survivors, then vote, filter and
+ * write them to the rank's share of the result arrays (the reference inserts them into its compact local map).  The
+ * result arrays are the concatenation over ranks; sort_results != 0 sorts them by key (S9: the tests compare sorted
+ * sets; the reference itself never sorts, so the timed baseline does not either). */
+int orc_finalize_ex(orc_ctx *c, int sort_results) {
   int nl = c->nl;
-  uint64_t total = 0;
-  for (int r = 0; r < c->nranks; r++) total += c->tables[r].num_elems;
-  orc_rec *recs = (orc_rec *)malloc((total ? total : 1) * sizeof(orc_rec));
-  if (!recs) return -1;
-  uint64_t n = 0, purged = 0, sum = 0, dropped = 0;
-  for (int r = 0; r < c->nranks; r++) {
-    orc_table *t = &c->tables[r];
-    dropped += t->num_dropped;
+  int nr = c->nranks;
+  uint64_t *cnt = (uint64_t *)calloc((size_t)nr + 1, 8);
+  uint64_t *purged_r = (uint64_t *)calloc((size_t)nr, 8), *sum_r = (uint64_t *)calloc((size_t)nr, 8);
+  if (!cnt || !purged_r || !sum_r) return -1;
+  /* scan 1: survivors per rank */
+#pragma omp parallel for schedule(dynamic, 1) num_threads(c->nthreads)
+  for (int r = 0; r < nr; r++) {
+    const orc_table *t = &c->tables[r];
+    uint64_t n = 0, p = 0;
     for (uint64_t s = 0; s < t->capacity; s++) {
       const uint64_t *ks = t->keys + s * nl;
       if (ks[nl - 1] == ~0ULL) continue;
-      orc_vals *v = &t->vals[s];
-      if (v->count < 2) { purged++; continue; }
+      const orc_vals *v = &t->vals[s];
+      if (v->count < 2) { p++; continue; }
       char l = orc_get_ext(v->left, v->count, c->dmin_thres);
       char rr = orc_get_ext(v->right, v->count, c->dmin_thres);
-      if (l == 'X' || l == 'F' || rr == 'X' || rr == 'F') { purged++; continue; }
-      memset(&recs[n], 0, sizeof(orc_rec));
-      memcpy(recs[n].key, ks, 8 * nl);
-      recs[n].count = v->count;
-      recs[n].left = l;
-      recs[n].right = rr;
-      sum += v->count;
+      if (l == 'X' || l == 'F' || rr == 'X' || rr == 'F') { p++; continue; }
       n++;
     }
+    cnt[r + 1] = n;
+    purged_r[r] = p;
   }
-  g_sort_nl = nl;
-  qsort(recs, n, sizeof(orc_rec), rec_cmp);
+  uint64_t total = 0, dropped = 0, purged = 0;
+  for (int r = 0; r < nr; r++) {
+    cnt[r + 1] += cnt[r];
+    total += c->tables[r].num_elems;
+    dropped += c->tables[r].num_dropped;
+    purged += purged_r[r];
+  }
+  const uint64_t n = cnt[nr];
   free(c->res_keys); free(c->res_counts); free(c->res_left); free(c->res_right);
   c->res_keys = (uint64_t *)malloc((n ? n : 1) * 8 * nl);
   c->res_counts = (uint16_t *)malloc((n ? n : 1) * 2);
   c->res_left = (char *)malloc(n ? n : 1);
   c->res_right = (char *)malloc(n ? n : 1);
-  if (!c->res_keys || !c->res_counts || !c->res_left || !c->res_right) { free(recs); return -1; }
-  for (uint64_t i = 0; i < n; i++) {
-    memcpy(c->res_keys + i * nl, recs[i].key, 8 * nl);
-    c->res_counts[i] = recs[i].count;
-    c->res_left[i] = recs[i].left;
-    c->res_right[i] = recs[i].right;
+  if (!c->res_keys || !c->res_counts || !c->res_left || !c->res_right) return -1;
+  /* scan 2: vote, filter, write */
+#pragma omp parallel for schedule(dynamic, 1) num_threads(c->nthreads)
+  for (int r = 0; r < nr; r++) {
+    const orc_table *t = &c->tables[r];
+    uint64_t o = cnt[r], sum = 0;
+    for (uint64_t s = 0; s < t->capacity; s++) {
+      const uint64_t *ks = t->keys + s * nl;
+      if (ks[nl - 1] == ~0ULL) continue;
+      const orc_vals *v = &t->vals[s];
+      if (v->count < 2) continue;
+      char l = orc_get_ext(v->left, v->count, c->dmin_thres);
+      char rr = orc_get_ext(v->right, v->count, c->dmin_thres);
+      if (l == 'X' || l == 'F' || rr == 'X' || rr == 'F') continue;
+      memcpy(c->res_keys + o * nl, ks, 8 * nl);
+      c->res_counts[o] = v->count;
+      c->res_left[o] = l;
+      c->res_right[o] = rr;
+      sum += v->count;
+      o++;
+    }
+    sum_r[r] = sum;
   }
-  free(recs);
+  uint64_t sum = 0;
+  for (int r = 0; r < nr; r++) sum += sum_r[r];
+  free(cnt); free(purged_r); free(sum_r);
+  if (sort_results && n > 1) {
+    orc_rec *recs = (orc_rec *)malloc(n * sizeof(orc_rec));
+    if (!recs) return -1;
+    for (uint64_t i = 0; i < n; i++) {
+      memset(&recs[i], 0, sizeof(orc_rec));
+      memcpy(recs[i].key, c->res_keys + i * nl, 8 * nl);
+      recs[i].count = c->res_counts[i];
+      recs[i].left = c->res_left[i];
+      recs[i].right = c->res_right[i];
+    }
+    g_sort_nl = nl;
+    qsort(recs, n, sizeof(orc_rec), rec_cmp);
+    for (uint64_t i = 0; i < n; i++) {
+      memcpy(c->res_keys + i * nl, recs[i].key, 8 * nl);
+      c->res_counts[i] = recs[i].count;
+      c->res_left[i] = recs[i].left;
+      c->res_right[i] = recs[i].right;
+    }
+    free(recs);
+  }
   c->nres = n;
   c->num_unique = total;
   c->num_purged = purged;
@@ -679,6 +725,8 @@ int orc_finalize(orc_ctx *c) {
   c->num_dropped = dropped;
   return 0;
 }
+
+int orc_finalize(orc_ctx *c) { return orc_finalize_ex(c, 1); }
 
 uint64_t orc_num_results(const orc_ctx *c) { return c->nres; }
 
@@ -727,7 +775,7 @@ uint64_t orc_dump_table(const orc_ctx *c, uint64_t *keys, uint16_t *counts, uint
 /* stats[]: 0 reads, 1 raw k-mers (kcount.cpp:86), 2 supermers sent, 3 k-mer
  * inserts attempted and not dropped, 4 unique before purge, 5 purged,
  * 6 results ("Total kmers", kcount.cpp:160), 7 sum of counts ("Total kmer
- * count sum", kcount_cpu.cpp:598), 8 dropped, 9 nranks, 10 nthreads */
+ * count sum", kcount_cpu.cpp:598), 8 dropped, 9 nranks, 10 nthreads, 11 table rehashes */
 void orc_get_stats(const orc_ctx *c, uint64_t *stats) {
   stats[0] = c->num_reads;
   stats[1] = c->raw_kmers;
@@ -740,6 +788,9 @@ void orc_get_stats(const orc_ctx *c, uint64_t *stats) {
   stats[8] = c->num_dropped;
   stats[9] = (uint64_t)c->nranks;
   stats[10] = (uint64_t)c->nthreads;
+  uint64_t grows = 0;
+  for (int r = 0; r < c->nranks; r++) grows += c->tables[r].num_grows;
+  stats[11] = grows;
 }
 
 /* k-mer words -> ACGT string (kmer.cpp to_string), for the dump format

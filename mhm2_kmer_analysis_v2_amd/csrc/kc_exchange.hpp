@@ -1,0 +1,205 @@
+// kc_exchange.hpp -- the intra-node shard exchange in C++ over RCCL (xGMI), for a C++/UPC++ host such as MHM2.
+//
+// Replaces the reference's only bulk exchange inside the node: the aggregated RPC of
+// ThreeTierAggrStore<Supermer>::update / flush_updates (src/kcount/kmer_dht.cpp:143-151,247-258) that carries every
+// supermer to the rank owning its k-mers.  One process per GPU, one ShardExchange per process:
+//
+//   per block of reads   kc_extract_partition          records binned by owner shard (compute stream)
+//                        ncclAllGather of the counts   N x N u64: everybody learns what it will receive
+//                        grouped ncclSend / ncclRecv   all-to-all-v of the records on a SIDE stream, so that it
+//                                                      overlaps the extraction of the next block
+//                        kc_insert_records             the rank's own share straight from its send buffer, what arrived
+//                                                      from the others once the side stream says so (an event, no host wait)
+//
+// Two send and two receive buffers alternate, so block i travels while block i-1 is inserted and block i+1 extracted.
+// Nothing else is communicated: ownership is a pure function of the k-mer (kc_owner), finalize is per shard.
+// xGMI is point to point: every rank ships 1/N of its records to each peer over that peer's own link, a few GB/s per
+// link at the rates the kernels reach -- far below a link's ~150 GB/s, so the exchange hides behind the extraction.
+//
+// Header-only over the C ABI (include/kcount_mi355.h) and <rccl/rccl.h>; no exceptions (MHM2 calls this inside UPC++
+// progress): every method returns a KC_* status, last_error() has the text.  The Python twin used by bench.py and the
+// tests is mhm2_kmer_analysis_v2_amd/dist.py (torch.distributed, same protocol).
+#pragma once
+#include <hip/hip_runtime_api.h>
+#include <rccl/rccl.h>
+
+#include <cstdint>
+#include <cstdio>
+#include <string>
+#include <vector>
+
+#include "../../include/kcount_mi355.h"
+
+namespace kcount_mi355 {
+
+class ShardExchange {
+  kc_ctx *ctx;
+  ncclComm_t comm;
+  int me, n, nl;
+  uint64_t seg;                    // records per destination segment of a send buffer
+  hipStream_t compute = nullptr;   // the context's stream (ours unless the caller gave one)
+  hipStream_t side = nullptr;      // RCCL's stream
+  bool own_compute = false;
+  uint64_t *send[2] = {nullptr, nullptr}, *recv[2] = {nullptr, nullptr};
+  uint64_t recv_cap[2] = {0, 0};
+  uint64_t *d_counts = nullptr, *d_all = nullptr;  // this rank's N counts; everybody's N x N
+  uint64_t *h_all = nullptr;                       // pinned
+  hipEvent_t arrived[2] = {nullptr, nullptr};      // side stream: block's records have landed in recv[i]
+  hipEvent_t consumed[2] = {nullptr, nullptr};     // compute stream: the inserts reading send[i] / recv[i] are done
+  bool used[2] = {false, false};
+  struct Pending { bool any = false; int buf = 0; uint64_t n_own = 0, n_recv = 0; } pending;
+  uint64_t blocks = 0, sent = 0, received = 0;
+  std::string err;
+
+  int fail(int status, const char *what, const char *detail) {
+    err = std::string(what) + ": " + detail;
+    return status;
+  }
+#define KCX_HIP(call)                                                                  \
+  do {                                                                                 \
+    hipError_t e_ = (call);                                                            \
+    if (e_ != hipSuccess) return fail(KC_ERR_HIP, #call, hipGetErrorString(e_));       \
+  } while (0)
+#define KCX_NCCL(call)                                                                 \
+  do {                                                                                 \
+    ncclResult_t r_ = (call);                                                          \
+    if (r_ != ncclSuccess) return fail(KC_ERR_HIP, #call, ncclGetErrorString(r_));     \
+  } while (0)
+#define KCX_KC(call)                                                                   \
+  do {                                                                                 \
+    int s_ = (call);                                                                   \
+    if (s_ != KC_OK) return fail(s_, #call, kc_last_error());                          \
+  } while (0)
+
+  // the previous block: its own share and what it received go into the table (compute stream, ordered by events)
+  int complete() {
+    if (!pending.any) return KC_OK;
+    const int b = pending.buf;
+    if (pending.n_own) KCX_KC(kc_insert_records(ctx, send[b] + (uint64_t)me * seg * nl, pending.n_own));
+    if (pending.n_recv) {
+      KCX_HIP(hipStreamWaitEvent(compute, arrived[b], 0));
+      KCX_KC(kc_insert_records(ctx, recv[b], pending.n_recv));
+    }
+    KCX_HIP(hipEventRecord(consumed[b], compute));
+    received += pending.n_own + pending.n_recv;
+    pending.any = false;
+    return KC_OK;
+  }
+
+ public:
+  // ctx: this rank's context (created with the same rank_me / rank_n as `comm`); seg_capacity: records one block may
+  // send to one shard (a block of R reads of length L needs about R * (L - k - 1) / rank_n * 1.25);
+  // compute_stream: the stream the context's kernels should run on, NULL = a stream of this object's own.
+  ShardExchange(kc_ctx *ctx_, ncclComm_t comm_, int rank_me, int rank_n, int num_longs, uint64_t seg_capacity,
+                hipStream_t compute_stream = nullptr)
+      : ctx(ctx_), comm(comm_), me(rank_me), n(rank_n), nl(num_longs), seg(seg_capacity), compute(compute_stream) {}
+  ShardExchange(const ShardExchange &) = delete;
+  ShardExchange &operator=(const ShardExchange &) = delete;
+
+  int init() {
+    if (!ctx || n < 1 || me < 0 || me >= n || nl < 1 || !seg) return fail(KC_ERR_INVALID_ARG, "ShardExchange", "bad arguments");
+    if (!compute) {
+      KCX_HIP(hipStreamCreateWithFlags(&compute, hipStreamNonBlocking));
+      own_compute = true;
+    }
+    KCX_KC(kc_set_stream(ctx, (void *)compute));
+    KCX_HIP(hipStreamCreateWithFlags(&side, hipStreamNonBlocking));
+    for (int b = 0; b < 2; b++) {
+      KCX_HIP(hipMalloc((void **)&send[b], (size_t)n * seg * nl * 8));
+      KCX_HIP(hipEventCreateWithFlags(&arrived[b], hipEventDisableTiming));
+      KCX_HIP(hipEventCreateWithFlags(&consumed[b], hipEventDisableTiming));
+    }
+    KCX_HIP(hipMalloc((void **)&d_counts, (size_t)n * 8));
+    KCX_HIP(hipMalloc((void **)&d_all, (size_t)n * n * 8));
+    KCX_HIP(hipHostMalloc((void **)&h_all, (size_t)n * n * 8, hipHostMallocDefault));
+    return KC_OK;
+  }
+
+  ~ShardExchange() {
+    if (side) (void)hipStreamSynchronize(side);
+    if (compute) (void)hipStreamSynchronize(compute);
+    for (int b = 0; b < 2; b++) {
+      if (send[b]) (void)hipFree(send[b]);
+      if (recv[b]) (void)hipFree(recv[b]);
+      if (arrived[b]) (void)hipEventDestroy(arrived[b]);
+      if (consumed[b]) (void)hipEventDestroy(consumed[b]);
+    }
+    if (d_counts) (void)hipFree(d_counts);
+    if (d_all) (void)hipFree(d_all);
+    if (h_all) (void)hipHostFree(h_all);
+    if (side) (void)hipStreamDestroy(side);
+    if (own_compute && compute) {
+      (void)kc_set_stream(ctx, nullptr);
+      (void)hipStreamDestroy(compute);
+    }
+  }
+
+  // count_kmers' loop body for one block of reads (src/kcount/kcount.cpp:71-90 + kmer_dht.cpp:247-250): extract, bin,
+  // ship.  bases / quals / offsets as for kc_extract_partition.  Collective: every rank calls it the same number of
+  // times (a rank that has run out of reads calls it with nreads = 0).
+  int add_block(const uint8_t *bases, const uint8_t *quals, const uint64_t *offsets, uint64_t nreads, int on_device) {
+    const int b = (int)(blocks & 1);
+    blocks++;
+    // send[b] / recv[b] were last read by the inserts of two blocks ago: the extraction below is ordered behind them by
+    // the compute stream itself, the transfers of this block by the event
+    std::vector<uint64_t> counts((size_t)n, 0);
+    if (nreads) KCX_KC(kc_extract_partition(ctx, bases, quals, offsets, nreads, on_device, send[b], seg, counts.data()));
+    // everybody's counts: N x N, row s = what rank s sends to each shard
+    KCX_HIP(hipMemcpyAsync(d_counts, counts.data(), (size_t)n * 8, hipMemcpyHostToDevice, side));
+    KCX_NCCL(ncclAllGather(d_counts, d_all, (size_t)n, ncclUint64, comm, side));
+    KCX_HIP(hipMemcpyAsync(h_all, d_all, (size_t)n * n * 8, hipMemcpyDeviceToHost, side));
+    KCX_HIP(hipStreamSynchronize(side));
+    uint64_t total = 0;
+    for (int s = 0; s < n; s++)
+      if (s != me) total += h_all[(size_t)s * n + me];
+    if (total > recv_cap[b]) {
+      if (used[b]) KCX_HIP(hipEventSynchronize(consumed[b]));
+      if (recv[b]) KCX_HIP(hipFree(recv[b]));
+      recv[b] = nullptr;
+      recv_cap[b] = total + total / 8 + 1024;
+      KCX_HIP(hipMalloc((void **)&recv[b], (size_t)recv_cap[b] * nl * 8));
+    }
+    // the previous block: its transfer has had this block's extraction to finish
+    int rc = complete();
+    if (rc) return rc;
+    // all-to-all-v of the records: one group of point-to-point transfers (each pair has its own xGMI link)
+    if (used[b]) KCX_HIP(hipStreamWaitEvent(side, consumed[b], 0));
+    KCX_NCCL(ncclGroupStart());
+    uint64_t pos = 0;
+    for (int d = 0; d < n; d++) {
+      if (d == me) continue;  // this rank's own share never travels
+      const uint64_t sc = counts[(size_t)d], rcv = h_all[(size_t)d * n + me];
+      if (rcv) KCX_NCCL(ncclRecv(recv[b] + pos * nl, (size_t)rcv * nl, ncclUint64, d, comm, side));
+      if (sc) KCX_NCCL(ncclSend(send[b] + (uint64_t)d * seg * nl, (size_t)sc * nl, ncclUint64, d, comm, side));
+      pos += rcv;
+      sent += sc;
+    }
+    KCX_NCCL(ncclGroupEnd());
+    KCX_HIP(hipEventRecord(arrived[b], side));
+    used[b] = true;
+    sent += counts[(size_t)me];
+    pending.any = true;
+    pending.buf = b;
+    pending.n_own = counts[(size_t)me];
+    pending.n_recv = total;
+    return KC_OK;
+  }
+
+  // KmerDHT::flush_updates (kmer_dht.cpp:252-258): the last block in flight is inserted; call before kc_finalize
+  int finish() {
+    int rc = complete();
+    if (rc) return rc;
+    KCX_KC(kc_flush(ctx));
+    return KC_OK;
+  }
+
+  uint64_t records_sent() const { return sent; }          // this rank's records, its own share included
+  uint64_t records_received() const { return received; }  // records inserted into this rank's table
+  const char *last_error() const { return err.c_str(); }
+  hipStream_t compute_stream() const { return compute; }
+#undef KCX_HIP
+#undef KCX_NCCL
+#undef KCX_KC
+};
+
+}  // namespace kcount_mi355

@@ -77,14 +77,27 @@ class ShardedKmerAnalysis:
     so that the exchange logic itself is what they exercise).
 
     Two send and two receive buffers: while block i travels (RCCL's own stream), block i-1 is inserted and
-    block i+1 is extracted on the compute stream."""
+    block i+1 is extracted on the compute stream.
 
-    def __init__(self, extract, insert, num_longs, seg_capacity, device, group=None):
+    Stream rule (GPU): a finished RCCL work orders only torch's CURRENT stream behind the transfer, so the library's
+    kernels must run on that stream or they could read `recv` before it has landed.  Pass the KmerCounter as
+    `counter` and this class puts it on torch's current stream of `device` (kc_set_stream); without one the caller
+    must have done so itself.  The C++ twin (csrc/kc_exchange.hpp) orders its two streams with events instead."""
+
+    def __init__(self, extract, insert, num_longs, seg_capacity, device, group=None, counter=None):
         self.extract, self.insert = extract, insert
         self.nl, self.seg = num_longs, seg_capacity
         self.group = group
         self.world = dist.get_world_size(group)
         self.device = device
+        if counter is not None and torch.device(device).type == "cuda":
+            stream = torch.cuda.current_stream(device)
+            if stream.cuda_stream == 0:
+                # the null stream reads as "use your own" to the library: give both a real one
+                stream = torch.cuda.Stream(device=device)
+                torch.cuda.set_stream(stream)
+            counter.set_stream(stream.cuda_stream)
+            self._stream = stream
         self.send = [torch.zeros(self.world * seg_capacity * num_longs, dtype=torch.int64, device=device) for _ in range(2)]
         self.recv = [None, None]
         self.pending = None
@@ -110,10 +123,9 @@ class ShardedKmerAnalysis:
         b = self.i % 2
         self.i += 1
         counts = self.extract(block, self.send[b], self.seg)
-        sc = torch.as_tensor([int(c) for c in counts], dtype=torch.int64, device=self.device)
-        rc = exchange_counts(sc, self.group)
-        sc_host = sc.cpu()
-        works, self.recv[b], n = start_exchange(self.send[b], sc_host, rc.cpu(), self.seg, self.nl, self.recv[b], self.group)
+        sc_host = torch.as_tensor([int(c) for c in counts], dtype=torch.int64)
+        rc = exchange_counts(sc_host.to(self.device), self.group).cpu()  # the one host round trip of a block
+        works, self.recv[b], n = start_exchange(self.send[b], sc_host, rc, self.seg, self.nl, self.recv[b], self.group)
         own, n_own = local_share(self.send[b], sc_host, self.seg, self.nl, self.group)
         self._complete()  # the previous block: its transfer has had this block's extraction to finish
         self.pending = (works, self.recv[b], n, own, n_own)

@@ -26,6 +26,34 @@ def test_adapters_compile_and_link(tmp_path):
     assert os.path.exists(build(tmp_path))
 
 
+def build_exchange(tmp):
+    exe = os.path.join(str(tmp), "test_exchange")
+    subprocess.check_call([HIPCC, "-std=c++17", "-O1", "-o", exe, os.path.join(ROOT, "tests", "cpp", "test_exchange.cpp"), "-L" + CSRC,
+                           "-lkcount_mi355", "-lrccl", "-Wl,-rpath," + CSRC])
+    return exe
+
+
+def test_rccl_exchange_compiles_and_links(tmp_path):
+    """kc_exchange.hpp (ShardExchange over rccl.h: all-gathered counts, grouped ncclSend/ncclRecv on a side stream)"""
+    assert os.path.exists(build_exchange(tmp_path))
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("k", [21, 51])
+def test_rccl_exchange_one_rank_matches_oracle(tmp_path, k):
+    """the C++ exchange driven like count_kmers + KmerDHT, one-member communicator (the box has one GPU): blocks,
+    counts through RCCL, inserts ordered by events; result = the oracle's dump"""
+    exe = build_exchange(tmp_path)
+    rng = np.random.default_rng(78)
+    reads, quals = random_reads(rng, 700, min_len=25, max_len=160, genome_len=2500, n_rate=0.0)
+    masked = ["".join(c.lower() if ord(x) < 33 + 20 else c for c, x in zip(r, q)) for r, q in zip(reads, quals)]
+    out = subprocess.run([exe, str(k)], input="\n".join(masked) + "\n", capture_output=True, text=True, check=True).stdout
+    got = [l[5:] for l in out.splitlines() if l.startswith("KMER ")]
+    (keys, counts, left, right), st = O.count_reads(reads, quals, k=k)
+    want = sorted("%s %d %s %s" % (O.kmer_to_string(keys[i], k), counts[i], chr(left[i]), chr(right[i])) for i in range(len(counts)))
+    assert got == want and len(want) > 50
+
+
 def test_compact_record_mix_is_a_bijection(tmp_path):
     """kc_feistel_fwd / kc_feistel_inv (host build of kc_common.hpp): a permutation with the stated inverse, evenly
     spread bucket / region / slot bits (tests/cpp/test_mix.cpp)."""

@@ -183,6 +183,31 @@ int kc_extract_partition_seq_block(kc_ctx *ctx, const char *seqs, uint64_t len, 
  * (gpu_hash_table.cpp:655-695) for records that arrived from other shards. */
 int kc_insert_records(kc_ctx *ctx, const uint64_t *d_records, uint64_t n);
 
+/* ---- the reference's wire format (runs mixed with unmodified MHM2 ranks) -------------------------------- */
+/* kcount_gpu::SupermerInfo (src/kcount/kcount-gpu/parse_and_pack.hpp:50-54), same layout */
+typedef struct kc_supermer {
+  int32_t target; /* KmerDHT::get_kmer_target_rank of the supermer's k-mers */
+  int32_t offset; /* first character in the block: the left neighbour of its first k-mer */
+  uint16_t len;   /* characters: its k-mers + k + 1 */
+} kc_supermer;
+/*
+ * ParseAndPackGPUDriver::process_seq_block + pack_seq_block (parse_and_pack.cpp:281-336): the supermers of a '_'-joined,
+ * case-masked block with the CPU backend's semantics (SeqBlockInserter::process_seq, kcount_cpu.cpp:73-103: maximal
+ * runs of k-mers with both neighbours and one target rank) and the block packed two characters per byte with the
+ * reference's nibble codes (parse_and_pack.cpp:196-213).  out: capacity entries (host), *n_out = how many there are
+ * (KC_ERR_CAPACITY if more than capacity: nothing else is lost, call again with room); *num_valid_kmers = k-mers
+ * covered; packed_out: (len + 1) / 2 bytes (host) or NULL.  The context's rank_n gives the number of targets.
+ */
+int kc_build_supermers(kc_ctx *ctx, const char *seqs, uint64_t len, int on_device, kc_supermer *out, uint32_t capacity,
+                       uint32_t *n_out, uint32_t *num_valid_kmers, uint8_t *packed_out);
+/*
+ * HashTableGPUDriver::insert_supermer_block (gpu_hash_table.cpp:655-679): 4-bit packed supermers as
+ * src/kcount/kcount_gpu.cpp:153-161 cuts them (odd nibbles masked to 0), joined by the byte '_' as
+ * HashTableGPUDriver::insert_supermer joins them; unpacked on the device (gpu_unpack_supermer_block's role) and
+ * inserted like kc_submit_seq_block.
+ */
+int kc_submit_packed_supermers(kc_ctx *ctx, const uint8_t *packed, uint64_t len, int on_device);
+
 /* KmerDHT::flush_updates -> HashTableInserter::flush_inserts (kmer_dht.cpp:252-258): wait for submitted work. */
 int kc_flush(kc_ctx *ctx);
 

@@ -74,6 +74,9 @@ SYMBOLS = {
                                        C.c_uint64, C.c_void_p]),
     "kc_extract_partition_seq_block": (C.c_int, [C.c_void_p, C.c_void_p, C.c_uint64, C.c_int, C.c_void_p, C.c_uint64, C.c_void_p]),
     "kc_insert_records": (C.c_int, [C.c_void_p, C.c_void_p, C.c_uint64]),
+    "kc_build_supermers": (C.c_int, [C.c_void_p, C.c_void_p, C.c_uint64, C.c_int, C.c_void_p, C.c_uint32, C.POINTER(C.c_uint32),
+                                      C.POINTER(C.c_uint32), C.c_void_p]),
+    "kc_submit_packed_supermers": (C.c_int, [C.c_void_p, C.c_void_p, C.c_uint64, C.c_int]),
     "kc_flush": (C.c_int, [C.c_void_p]),
     "kc_finalize": (C.c_int, [C.c_void_p, C.POINTER(kc_result)]),
     "kc_copy_results": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]),

@@ -19,6 +19,7 @@
 
 #include "../../include/kcount_mi355.h"
 #include "kc_bucketed.hpp"
+#include "kc_supermer.hpp"
 
 using namespace kc;
 
@@ -86,6 +87,13 @@ struct kc_ctx {
   uint32_t *d_index;  // lookup index over the results (built on first kc_lookup)
   uint64_t index_cap;
   kc_synth_table *d_synth;
+  // scratch of the reference-wire entry points (kc_build_supermers, kc_submit_packed_supermers)
+  uint8_t *d_sm_bytes;    // block / unpacked block
+  uint8_t *d_sm_packed;   // packed block / packed supermers
+  int32_t *d_sm_targets;
+  SupermerInfo *d_sm_out;
+  uint32_t *d_sm_ctr;     // n_out, n_kmers, too_long, + a u64 "bad character" flag behind them
+  size_t sm_bytes_cap, sm_packed_cap, sm_targets_cap, sm_out_cap;
   // host-side stats
   uint64_t num_reads, num_bases, num_gpu_calls;
   uint64_t purged, sum_counts, unique_at_finalize;
@@ -378,6 +386,11 @@ extern "C" void kc_destroy(kc_ctx *c) {
   if (c->d_stage_quals) (void)hipFree(c->d_stage_quals);
   if (c->d_stage_offsets) (void)hipFree(c->d_stage_offsets);
   if (c->d_synth) (void)hipFree(c->d_synth);
+  if (c->d_sm_bytes) (void)hipFree(c->d_sm_bytes);
+  if (c->d_sm_packed) (void)hipFree(c->d_sm_packed);
+  if (c->d_sm_targets) (void)hipFree(c->d_sm_targets);
+  if (c->d_sm_out) (void)hipFree(c->d_sm_out);
+  if (c->d_sm_ctr) (void)hipFree(c->d_sm_ctr);
   host_pipe_free(c);
   bk_free(c);
   if (c->d_cb) (void)hipFree(c->d_cb);
@@ -1142,6 +1155,98 @@ extern "C" int kc_submit_seq_block(kc_ctx *c, const char *seqs, uint64_t len, in
   c->num_bases += len;
   if (!on_device) HIPCHK(hipStreamSynchronize(c->stream));  // caller's buffer is free to change
   return KC_OK;
+}
+
+// ---- the reference's wire format ----------------------------------------------------------------------------------
+template <typename T>
+static int grow_dev(T **p, size_t *cap, size_t need) {
+  if (need <= *cap) return KC_OK;
+  if (*p) HIPCHK(hipFree(*p));
+  *p = nullptr;
+  *cap = 0;
+  HIPCHK(hipMalloc((void **)p, need * sizeof(T)));
+  *cap = need;
+  return KC_OK;
+}
+
+extern "C" int kc_build_supermers(kc_ctx *c, const char *seqs, uint64_t len, int on_device, kc_supermer *out, uint32_t capacity,
+                                  uint32_t *n_out, uint32_t *num_valid_kmers, uint8_t *packed_out) {
+  static_assert(sizeof(kc_supermer) == sizeof(SupermerInfo) && sizeof(kc_supermer) == 12, "layout of kcount_gpu::SupermerInfo");
+  if (!c || !n_out || (len && !seqs) || (capacity && !out) || len >= (1ULL << 31)) return KC_ERR_INVALID_ARG;
+  *n_out = 0;
+  if (num_valid_kmers) *num_valid_kmers = 0;
+  HIPCHK(hipSetDevice(c->cfg.device));
+  if (!len) return KC_OK;
+  int rc = grow_dev(&c->d_sm_targets, &c->sm_targets_cap, (size_t)len);
+  if (!rc) rc = grow_dev(&c->d_sm_out, &c->sm_out_cap, (size_t)std::max<uint32_t>(capacity, 1));
+  if (!rc) rc = grow_dev(&c->d_sm_packed, &c->sm_packed_cap, (size_t)(len + 1) / 2);
+  if (!rc && !on_device) rc = grow_dev(&c->d_sm_bytes, &c->sm_bytes_cap, (size_t)len);
+  if (rc) return rc;
+  if (!c->d_sm_ctr) HIPCHK(hipMalloc((void **)&c->d_sm_ctr, 32));
+  HIPCHK(hipMemsetAsync(c->d_sm_ctr, 0, 32, c->stream));
+  const uint8_t *d = (const uint8_t *)seqs;
+  if (!on_device) {
+    HIPCHK(hipMemcpyAsync(c->d_sm_bytes, seqs, len, hipMemcpyHostToDevice, c->stream));
+    d = c->d_sm_bytes;
+  }
+  const unsigned nblk = (unsigned)((len + 255) / 256);
+  uint64_t *d_bad = (uint64_t *)(c->d_sm_ctr + 4);
+  switch (c->nl) {
+    case 1: hipLaunchKernelGGL(kc_supermer_targets_kernel<1>, dim3(nblk), dim3(256), 0, c->stream, d, len, c->k, (uint32_t)c->cfg.rank_n, c->d_sm_targets, d_bad); break;
+    case 2: hipLaunchKernelGGL(kc_supermer_targets_kernel<2>, dim3(nblk), dim3(256), 0, c->stream, d, len, c->k, (uint32_t)c->cfg.rank_n, c->d_sm_targets, d_bad); break;
+    case 3: hipLaunchKernelGGL(kc_supermer_targets_kernel<3>, dim3(nblk), dim3(256), 0, c->stream, d, len, c->k, (uint32_t)c->cfg.rank_n, c->d_sm_targets, d_bad); break;
+    default: hipLaunchKernelGGL(kc_supermer_targets_kernel<4>, dim3(nblk), dim3(256), 0, c->stream, d, len, c->k, (uint32_t)c->cfg.rank_n, c->d_sm_targets, d_bad); break;
+  }
+  hipLaunchKernelGGL(kc_supermer_build_kernel, dim3(nblk), dim3(256), 0, c->stream, c->d_sm_targets, len, c->k, c->d_sm_out, capacity,
+                     c->d_sm_ctr, c->d_sm_ctr + 1, c->d_sm_ctr + 2);
+  hipLaunchKernelGGL(kc_pack_seqs_kernel, dim3((unsigned)(((len + 1) / 2 + 255) / 256)), dim3(256), 0, c->stream, d, len, c->d_sm_packed);
+  c->num_gpu_calls += 3;
+  HIPCHK(hipGetLastError());
+  uint32_t h[6];
+  HIPCHK(hipMemcpyAsync(h, c->d_sm_ctr, 24, hipMemcpyDeviceToHost, c->stream));
+  HIPCHK(hipStreamSynchronize(c->stream));
+  if (h[4] | h[5]) return KC_ERR_BAD_BASE;
+  if (h[2]) {
+    snprintf(g_last_error, sizeof(g_last_error), "a supermer is longer than 65535 characters");
+    return KC_ERR_INVALID_ARG;
+  }
+  *n_out = h[0];
+  if (num_valid_kmers) *num_valid_kmers = h[1];
+  if (h[0] > capacity) {
+    snprintf(g_last_error, sizeof(g_last_error), "%u supermers, room for %u", h[0], capacity);
+    return KC_ERR_CAPACITY;
+  }
+  if (h[0]) HIPCHK(hipMemcpy(out, c->d_sm_out, (size_t)h[0] * sizeof(kc_supermer), hipMemcpyDeviceToHost));
+  if (packed_out) HIPCHK(hipMemcpy(packed_out, c->d_sm_packed, (size_t)(len + 1) / 2, hipMemcpyDeviceToHost));
+  return KC_OK;
+}
+
+extern "C" int kc_submit_packed_supermers(kc_ctx *c, const uint8_t *packed, uint64_t len, int on_device) {
+  if (!c || (len && !packed)) return KC_ERR_INVALID_ARG;
+  if (c->finalized || c->bk_level2) return KC_ERR_STATE;
+  HIPCHK(hipSetDevice(c->cfg.device));
+  if (!len) return KC_OK;
+  // the unpacked block of the previous call may still be read by its kernels
+  HIPCHK(hipStreamSynchronize(c->stream));
+  int rc = grow_dev(&c->d_sm_bytes, &c->sm_bytes_cap, (size_t)len * 2);
+  if (!rc && !on_device) rc = grow_dev(&c->d_sm_packed, &c->sm_packed_cap, (size_t)len);
+  if (rc) return rc;
+  if (!c->d_sm_ctr) HIPCHK(hipMalloc((void **)&c->d_sm_ctr, 32));
+  HIPCHK(hipMemsetAsync(c->d_sm_ctr, 0, 32, c->stream));
+  const uint8_t *d = packed;
+  if (!on_device) {
+    HIPCHK(hipMemcpyAsync(c->d_sm_packed, packed, len, hipMemcpyHostToDevice, c->stream));
+    d = c->d_sm_packed;
+  }
+  uint64_t *d_bad = (uint64_t *)(c->d_sm_ctr + 4);
+  hipLaunchKernelGGL(kc_unpack_supermers_kernel, dim3((unsigned)((len + 255) / 256)), dim3(256), 0, c->stream, d, len, c->d_sm_bytes, d_bad);
+  c->num_gpu_calls++;
+  HIPCHK(hipGetLastError());
+  uint32_t h[2];
+  HIPCHK(hipMemcpyAsync(h, d_bad, 8, hipMemcpyDeviceToHost, c->stream));
+  HIPCHK(hipStreamSynchronize(c->stream));  // also: the caller's buffer is free to change
+  if (h[0] | h[1]) return KC_ERR_BAD_BASE;  // a nibble above 9 (reference: WARN "index out of range for to_base")
+  return kc_submit_seq_block(c, (const char *)c->d_sm_bytes, len * 2, 1);
 }
 
 extern "C" int kc_extract_partition(kc_ctx *c, const uint8_t *bases, const uint8_t *quals, const uint64_t *offsets, uint64_t nreads,

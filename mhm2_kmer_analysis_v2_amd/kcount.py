@@ -144,6 +144,25 @@ class KmerCounter:
               "kc_extract_partition")
         return counts
 
+    def build_supermers(self, block, capacity=None):
+        """ParseAndPackGPUDriver::process_seq_block + pack_seq_block on a '_'-joined case-masked block (bytes):
+        returns (targets i32, offsets i32, lens u16, num_valid_kmers, packed u8[(len+1)//2])."""
+        blk = np.frombuffer(block, dtype=np.uint8) if isinstance(block, (bytes, bytearray)) else np.ascontiguousarray(block, dtype=np.uint8)
+        cap = capacity if capacity is not None else max(16, len(blk))
+        out = np.zeros(cap, dtype=np.dtype([("target", np.int32), ("offset", np.int32), ("len", np.uint16), ("pad", np.uint16)]))
+        packed = np.zeros((len(blk) + 1) // 2, dtype=np.uint8)
+        n, nk = C.c_uint32(0), C.c_uint32(0)
+        check(lib().kc_build_supermers(self._h, blk.ctypes.data, len(blk), 0, out.ctypes.data, cap, C.byref(n), C.byref(nk),
+                                       packed.ctypes.data), "kc_build_supermers")
+        out = out[:n.value]
+        return out["target"].copy(), out["offset"].copy(), out["len"].copy(), nk.value, packed
+
+    def submit_packed_supermers(self, packed):
+        """4-bit packed supermers joined by the byte '_' (HashTableGPUDriver::insert_supermer's buffer)."""
+        pp, dev = _ptr(packed)
+        n = packed.numel() if hasattr(packed, "numel") else len(packed)
+        check(lib().kc_submit_packed_supermers(self._h, pp, n, 1 if dev else 0), "kc_submit_packed_supermers")
+
     def insert_records(self, records, n):
         pr, _ = _ptr(records)
         check(lib().kc_insert_records(self._h, pr, n), "kc_insert_records")

@@ -62,6 +62,8 @@ def lib():
         L.orc_add_reads.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_uint64]
         L.orc_insert_supermer.restype = C.c_int
         L.orc_insert_supermer.argtypes = [C.c_void_p, C.c_int, C.c_char_p, C.c_int]
+        L.orc_build_supermers.restype = C.c_int
+        L.orc_build_supermers.argtypes = [C.c_void_p, C.c_char_p, C.c_int, C.c_void_p, C.c_void_p, C.c_void_p]
         L.orc_finalize.restype = C.c_int
         L.orc_finalize.argtypes = [C.c_void_p]
         L.orc_finalize_ex.restype = C.c_int
@@ -174,6 +176,18 @@ class Oracle:
         rc = lib().orc_insert_supermer(self._h, target, b, len(b))
         if rc:
             raise RuntimeError("orc_insert_supermer failed: %d" % rc)
+
+    def supermers(self, masked_read):
+        """SeqBlockInserter::process_seq on one case-masked read: [(target, start, length)] (kcount_cpu.cpp:73-103)."""
+        b = masked_read.encode() if isinstance(masked_read, str) else masked_read
+        n = max(len(b), 1)
+        t = np.zeros(n, dtype=np.int32)
+        s = np.zeros(n, dtype=np.int32)
+        ln = np.zeros(n, dtype=np.int32)
+        m = lib().orc_build_supermers(self._h, b, len(b), t.ctypes.data, s.ctypes.data, ln.ctypes.data)
+        if m < 0:
+            raise MemoryError
+        return [(int(t[i]), int(s[i]), int(ln[i])) for i in range(m)]
 
     def finalize_unsorted(self):
         """Vote, purge and collect like the reference does (per rank, in parallel, no sort); returns the number of

@@ -450,13 +450,13 @@ static int emit_supermer(orc_ctx *c, int tid, int target, const char *s, uint32_
   return bb_push(b, s, len);
 }
 
-/* sender: count_kmers body (kcount.cpp:78-87) + SeqBlockInserter::process_seq
- * (kcount_cpu.cpp:73-103).  seq is a private, already case-masked copy. */
-static int process_seq(orc_ctx *c, int tid, const char *seq, int len, uint64_t *kbuf, uint64_t *n_super) {
-  int k = c->k, nl = c->nl;
+/* SeqBlockInserter::process_seq (kcount_cpu.cpp:73-103) as a list: the supermers of one case-masked read as
+ * (target, start, length) over the read.  Returns how many (they never number more than len); kbuf holds the read's
+ * k-mers afterwards. */
+static int supermers_of(const orc_ctx *c, const char *seq, int len, uint64_t *kbuf, int *targets, int *starts, int *lens) {
+  int k = c->k, nl = c->nl, n = 0;
   if (len < k + 2) return 0; /* nothing can be emitted (S1) */
-  int nk = orc_get_kmers(seq, len, k, kbuf);
-  (void)nk;
+  orc_get_kmers(seq, len, k, kbuf);
   /* targets of the canonical k-mers 1 .. len-k-1 */
   uint64_t rc[ORC_MAX_LONGS];
   int start = 0; /* supermer = seq[start .. end] */
@@ -471,16 +471,39 @@ static int process_seq(orc_ctx *c, int tid, const char *seq, int len, uint64_t *
       start = 0;
     } else if (target != prev_target) {
       /* supermer so far covers seq[start .. i+k-1] */
-      if (emit_supermer(c, tid, prev_target, seq + start, (uint32_t)(i + k - start))) return -1;
-      (*n_super)++;
+      targets[n] = prev_target; starts[n] = start; lens[n] = i + k - start; n++;
       start = i - 1;
       prev_target = target;
     }
   }
   /* final supermer reaches the end of the read: seq[start .. len-1] */
-  if (emit_supermer(c, tid, prev_target, seq + start, (uint32_t)(len - start))) return -1;
-  (*n_super)++;
-  return 0;
+  targets[n] = prev_target; starts[n] = start; lens[n] = len - start; n++;
+  return n;
+}
+
+/* the same through the library boundary, for tests of the wire format: arrays of at least len entries */
+int orc_build_supermers(const orc_ctx *c, const char *seq, int len, int *targets, int *starts, int *lens) {
+  uint64_t *kbuf = (uint64_t *)malloc(((size_t)len + 1) * 8 * c->nl);
+  if (!kbuf) return -1;
+  int n = supermers_of(c, seq, len, kbuf, targets, starts, lens);
+  free(kbuf);
+  return n;
+}
+
+/* sender: count_kmers body (kcount.cpp:78-87) + SeqBlockInserter::process_seq
+ * (kcount_cpu.cpp:73-103).  seq is a private, already case-masked copy. */
+static int process_seq(orc_ctx *c, int tid, const char *seq, int len, uint64_t *kbuf, uint64_t *n_super) {
+  if (len < c->k + 2) return 0;
+  int *tr = (int *)malloc(3 * (size_t)len * sizeof(int));
+  if (!tr) return -1;
+  int n = supermers_of(c, seq, len, kbuf, tr, tr + len, tr + 2 * len);
+  int err = 0;
+  for (int i = 0; i < n && !err; i++) {
+    if (emit_supermer(c, tid, tr[i], seq + tr[len + i], (uint32_t)tr[2 * len + i])) err = -1;
+    (*n_super)++;
+  }
+  free(tr);
+  return err;
 }
 
 /* receiver: HashTableInserter::insert_supermer -> insert_supermer_from_read ->

@@ -32,19 +32,40 @@ int main(int argc, char **argv) {
     ht[r]->init(r, R, k, 100000, 0, 10000, 0, msgs, warnings, false);
   }
   if (mode == "records") {
-    ParseAndPackDriver pnp(0, R, 33, k, kc_num_longs(k), 15, t);
+    ParseAndPackDriver pnp(0, R, 33, k, kc_num_longs(k), 15, t, /*records_mode=*/true);
     unsigned nvalid = 0;
     if (!pnp.process_seq_block(block, nvalid)) return 2;
     for (int r = 0; r < R; r++)
       ht[r]->insert_records(pnp.records() + (size_t)r * pnp.segment_capacity() * kc_num_longs(k), pnp.counts()[r]);
+  } else if (mode == "wire") {
+    // The reference's own flow, step for step as its host file drives the two drivers (process_block,
+    // src/kcount/kcount_gpu.cpp:110-165): supermers and the packed block from the sender driver, every supermer's bytes
+    // cut out of the packed block with the odd nibbles masked, handed to the driver of its target rank.
+    int m = k * 2 / 3 + 1;
+    m = m < 15 ? 15 : m > 27 ? 27 : m;
+    ParseAndPackDriver pnp(0, R, 33, k, kc_num_longs(k), m < k ? m : k, t);
+    unsigned nvalid = 0;
+    if (!pnp.process_seq_block(block, nvalid)) return 2;
+    pnp.pack_seq_block(block);
+    uint64_t covered = 0;
+    for (size_t i = 0; i < pnp.supermers.size(); i++) {
+      const int target = pnp.supermers[i].target, offset = pnp.supermers[i].offset, len = pnp.supermers[i].len;
+      int packed_len = len / 2;
+      if (offset % 2 || len % 2) packed_len++;
+      std::string seq = pnp.packed_seqs.substr(offset / 2, packed_len);
+      if (offset % 2) seq[0] &= 15;
+      if ((offset + len) % 2) seq[seq.length() - 1] &= (char)240;
+      if (target < 0 || target >= R) return 4;
+      ht[target]->insert_supermer(seq, 1);
+      covered += len - k - 1;
+    }
+    if (covered != nvalid) return 5;  // every k-mer with two neighbours is in exactly one supermer
+    auto [tf, tk] = pnp.get_elapsed_times();
+    if (!(tf > 0 && tk > 0 && tf >= tk)) return 6;
   } else {
-    // supermer path: whole reads as ASCII supermers to rank 0 only works for R == 1 semantics, so route by
-    // giving every read to both and letting each keep what it owns is not possible here: use one shard
+    // whole reads as supermers into one shard
     delete ht[1];
     ht[1] = nullptr;
-    delete ht[0];
-    ht[0] = new HashTableDriver<32>();
-    ht[0]->init(0, 1, k, 100000, 0, 10000, 0, msgs, warnings, false);
     size_t p = 0;
     while (p < block.size()) {
       size_t e = block.find('_', p);
@@ -69,6 +90,9 @@ int main(int argc, char **argv) {
     uint64_t dropped, unique, purged;
     ht[r]->done_all_inserts(dropped, unique, purged);
     if (dropped) return 3;
+    double t_ins = 0, t_ker = 0;
+    ht[r]->get_elapsed_time(t_ins, t_ker);
+    if (!(t_ins > 0 && t_ker > 0)) return 7;  // the timers are filled (gpu_hash_table.hpp:172)
     ht[r]->begin_iterate();
     while (true) {
       auto [key, val] = ht[r]->get_next_entry();

@@ -64,7 +64,7 @@ def test_compact_record_mix_is_a_bijection(tmp_path):
 
 
 @pytest.mark.gpu
-@pytest.mark.parametrize("mode", ["records", "ascii", "packed"])
+@pytest.mark.parametrize("mode", ["records", "ascii", "packed", "wire"])
 def test_cpp_driver_matches_oracle(tmp_path, mode):
     k = 21
     exe = build(tmp_path)

@@ -226,7 +226,7 @@ def main():
             offs = d_offs[r0:r1 + 1] - d_offs[r0]
             return kc.extract_partition(d_bases[r0 * L:], d_quals[r0 * L:], offs, send, seg_cap, nreads=r1 - r0)
 
-        sharded = ShardedKmerAnalysis(extract, lambda recv, n: kc.insert_records(recv, n), nl, seg, dev, counter=kc)
+        sharded = ShardedKmerAnalysis(extract, lambda recv, n: kc.insert_records(recv, n), kc.rec_nl, seg, dev, counter=kc)
 
     def step():
         kc.reset()

@@ -29,7 +29,7 @@ extern "C" {
 enum {
   KC_OK = 0,
   KC_ERR_INVALID_ARG = -1,
-  KC_ERR_UNSUPPORTED_K = -2, /* k < 3, k > 127, or k % 32 in {30, 31} (no room for the packed extension bits) */
+  KC_ERR_UNSUPPORTED_K = -2, /* k < 3 or k > 125 (126 and 127 would need a fifth record word) */
   KC_ERR_NO_DEVICE = -3,     /* HIP runtime reports no usable gfx950 device */
   KC_ERR_HIP = -4,           /* a HIP call failed; kc_last_error() has the text */
   KC_ERR_OUT_OF_MEMORY = -5,
@@ -115,6 +115,10 @@ int kc_device_count(void);       /* 0 without a GPU; never aborts */
 
 /* Kmer<MAX_K>::N_LONGS for the MAX_K the reference would pick: k/32+1 (src/main.cpp:169-190, src/kmer.hpp:64). */
 int kc_num_longs(int kmer_len);
+/* Words of one k-mer RECORD on the shard wire (kc_extract_partition / kc_insert_records): kc_num_longs, plus one when
+ * k % 32 is 30 or 31 (the last key word then has no six spare bits for the two extension codes, which ride in a word of
+ * their own).  Results, dumps and lookups always use kc_num_longs. */
+int kc_record_longs(int kmer_len);
 /* Shard that owns a canonical k-mer (role of KmerDHT::get_kmer_target_rank,
  * src/kcount/kmer_dht.cpp:192-196; any deterministic function of the k-mer
  * gives the same final set).  Host-callable. */
@@ -167,8 +171,8 @@ int kc_submit_seq_block(kc_ctx *ctx, const char *seqs, uint64_t len, int on_devi
  * Sharded flow, sender side: extract k-mer records from a block of reads and
  * bin them by owner shard (replaces parse_and_pack + build_supermers + the
  * per-supermer ThreeTierAggrStore::update of kmer_dht.cpp:247-250).  Records of
- * shard d land in d_records[d*seg_capacity*num_longs ...]; h_counts[d] receives
- * how many.  A record is num_longs words: the canonical k-mer with the two
+ * shard d land in d_records[d*seg_capacity*L ...] with L = kc_record_longs(k); h_counts[d] receives
+ * how many.  A record is L words: the canonical k-mer with the two
  * extension codes in the low 6 bits of its last word (left | right<<3; 0-3 =
  * ACGT, 4 = none).  KC_ERR_CAPACITY if a segment would overflow (nothing is lost:
  * the table is untouched, call again with more room).

@@ -61,6 +61,7 @@ SYMBOLS = {
     "kc_last_error": (C.c_char_p, []),
     "kc_device_count": (C.c_int, []),
     "kc_num_longs": (C.c_int, [C.c_int]),
+    "kc_record_longs": (C.c_int, [C.c_int]),
     "kc_owner": (C.c_int, [C.c_void_p, C.c_int, C.c_int]),
     "kc_owner_reference": (C.c_int, [C.c_void_p, C.c_int, C.c_int]),
     "kc_create": (C.c_void_p, [C.POINTER(kc_config), C.POINTER(C.c_int)]),

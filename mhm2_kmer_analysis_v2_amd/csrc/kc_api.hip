@@ -52,7 +52,8 @@ struct kc_ctx {
   std::vector<kt_pending> kt_pend;
   uint64_t kt_launches[KT_COUNT];
   double kt_ms[KT_COUNT];
-  int k, nl;
+  int k, nl;   // nl: words of a k-mer inside the library (kc_record_longs)
+  int nl_ext;  // the reference's width of the same k-mer (kc_num_longs): results, dumps, lookups
   hipStream_t own_stream, stream;
   // table arena: keys then vals
   uint8_t *arena;
@@ -80,6 +81,7 @@ struct kc_ctx {
   } hp;
   // results
   uint64_t *d_out_keys;
+  uint64_t *d_out_keys_ext;  // the results' keys at the reference's width, where that differs (made by kc_finalize)
   uint16_t *d_out_counts;
   uint8_t *d_out_left, *d_out_right;
   uint64_t out_cap, out_n;
@@ -270,21 +272,26 @@ extern "C" int kc_device_count(void) {
 
 extern "C" int kc_num_longs(int k) { return k / 32 + 1; }
 
+// Words of a k-mer inside the library and of a record on the shard wire: the two extension codes ride in the six spare
+// low bits of the last word, and when k % 32 is 30 or 31 that word has none to spare, so those k get one word more
+// (key word zero, extension codes only).  Results, dumps and lookups keep the reference's width (kc_num_longs).
+extern "C" int kc_record_longs(int k) { return k / 32 + 1 + ((k % 32) >= 30 ? 1 : 0); }
+
 static int check_k(int k) {
   if (k < 3 || k > 127) return KC_ERR_UNSUPPORTED_K;
-  int m = k % 32;
-  if (m == 30 || m == 31) return KC_ERR_UNSUPPORTED_K;  // the last word has no 6 spare bits
+  if (kc_record_longs(k) > KC_MAX_LONGS) return KC_ERR_UNSUPPORTED_K;  // k = 126, 127: a fifth word would be needed
   return KC_OK;
 }
 
 extern "C" int kc_owner(const uint64_t *w, int k, int rank_n) {
   if (!w || check_k(k) || rank_n < 1) return KC_ERR_INVALID_ARG;
-  uint64_t h;
-  switch (kc_num_longs(k)) {
-    case 1: { uint64_t a[1] = {w[0]}; h = kc_hash<1>(a); break; }
-    case 2: { uint64_t a[2] = {w[0], w[1]}; h = kc_hash<2>(a); break; }
-    case 3: { uint64_t a[3] = {w[0], w[1], w[2]}; h = kc_hash<3>(a); break; }
-    default: { uint64_t a[4] = {w[0], w[1], w[2], w[3]}; h = kc_hash<4>(a); break; }
+  uint64_t a[KC_MAX_LONGS] = {0, 0, 0, 0}, h;
+  for (int j = 0; j < kc_num_longs(k); j++) a[j] = w[j];  // the caller's k-mer has the reference's width
+  switch (kc_record_longs(k)) {
+    case 1: { uint64_t x[1] = {a[0]}; h = kc_hash<1>(x); break; }
+    case 2: { uint64_t x[2] = {a[0], a[1]}; h = kc_hash<2>(x); break; }
+    case 3: { uint64_t x[3] = {a[0], a[1], a[2]}; h = kc_hash<3>(x); break; }
+    default: h = kc_hash<4>(a); break;
   }
   return (int)kc_owner_of_hash(h, (uint32_t)rank_n);
 }
@@ -297,6 +304,14 @@ extern "C" int kc_owner_reference(const uint64_t *w, int k, int rank_n) {
     case 3: { uint64_t a[3] = {w[0], w[1], w[2]}, r[3]; kc_revcomp<3>(a, k, r); return (int)::kc_reference_owner<3>(a, r, k, (uint32_t)rank_n); }
     default: { uint64_t a[4] = {w[0], w[1], w[2], w[3]}, r[4]; kc_revcomp<4>(a, k, r); return (int)::kc_reference_owner<4>(a, r, k, (uint32_t)rank_n); }
   }
+}
+
+// keys between the library's width and the reference's (they differ when k % 32 is 30 or 31): the words beyond the
+// narrower width are zero
+__global__ void kc_rewidth_keys_kernel(const uint64_t *src, uint64_t *dst, uint64_t n, int nl_src, int nl_dst) {
+  const uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= n) return;
+  for (int j = 0; j < nl_dst; j++) dst[i * nl_dst + j] = j < nl_src ? src[i * nl_src + j] : 0ULL;
 }
 
 // ---- context -----------------------------------------------------------------------------------
@@ -342,7 +357,8 @@ extern "C" kc_ctx *kc_create(const kc_config *cfg, int *status) {
     c->cfg = *cfg;
     if (c->cfg.dmin_thres <= 0) c->cfg.dmin_thres = 2;
     c->k = cfg->kmer_len;
-    c->nl = kc_num_longs(c->k);
+    c->nl = kc_record_longs(c->k);
+    c->nl_ext = kc_num_longs(c->k);
     st = create_impl(c);
     if (st) {
       kc_destroy(c);
@@ -362,6 +378,8 @@ static void free_index(kc_ctx *c) {
 static void free_results(kc_ctx *c) {
   free_index(c);
   if (c->d_out_keys) (void)hipFree(c->d_out_keys);
+  if (c->d_out_keys_ext) (void)hipFree(c->d_out_keys_ext);
+  c->d_out_keys_ext = nullptr;
   if (c->d_out_counts) (void)hipFree(c->d_out_counts);
   if (c->d_out_left) (void)hipFree(c->d_out_left);
   if (c->d_out_right) (void)hipFree(c->d_out_right);
@@ -414,11 +432,14 @@ extern "C" int kc_reset(kc_ctx *c, int new_k) {
   HIPCHK(hipSetDevice(c->cfg.device));
   HIPCHK(hipStreamSynchronize(c->stream));
   const int old_nl = c->nl, old_k = c->k;
-  if (kc_num_longs(new_k) != old_nl) free_results(c);  // else the result arrays are reused by the next finalize
+  if (kc_record_longs(new_k) != old_nl) free_results(c);  // else the result arrays are reused by the next finalize
   c->out_n = 0;
   c->k = new_k;
   c->cfg.kmer_len = new_k;
-  c->nl = kc_num_longs(new_k);
+  c->nl = kc_record_longs(new_k);
+  c->nl_ext = kc_num_longs(new_k);
+  if (c->d_out_keys_ext) (void)hipFree(c->d_out_keys_ext);
+  c->d_out_keys_ext = nullptr;
   // re-carve the same arena for the new word count: largest power of two that fits
   uint64_t cap = 1;
   while (table_bytes_for(cap << 1, c->nl) <= c->arena_bytes) cap <<= 1;
@@ -1719,13 +1740,24 @@ extern "C" int kc_finalize(kc_ctx *c, kc_result *out) {
     c->purged = c->h_ctrs[CTR_PURGED];
     c->sum_counts = c->h_ctrs[CTR_SUM_COUNTS];
     c->unique_at_finalize = c->h_ctrs[CTR_ENTRIES] + c->h_cb[CB_ENTRIES];
+    if (c->nl != c->nl_ext) {  // k % 32 in {30, 31}: the caller sees the reference's width
+      if (c->d_out_keys_ext) HIPCHK(hipFree(c->d_out_keys_ext));
+      c->d_out_keys_ext = nullptr;
+      HIPCHK(hipMalloc((void **)&c->d_out_keys_ext, std::max<uint64_t>(c->out_n, 1) * c->nl_ext * 8));
+      if (c->out_n) {
+        hipLaunchKernelGGL(kc_rewidth_keys_kernel, dim3((unsigned)((c->out_n + 255) / 256)), dim3(256), 0, c->stream, c->d_out_keys,
+                           c->d_out_keys_ext, c->out_n, c->nl, c->nl_ext);
+        HIPCHK(hipGetLastError());
+        HIPCHK(hipStreamSynchronize(c->stream));
+      }
+    }
     c->finalized = true;
   }
   if (out) {
     out->n = c->out_n;
-    out->num_longs = c->nl;
+    out->num_longs = c->nl_ext;
     out->reserved = 0;
-    out->d_keys = c->d_out_keys;
+    out->d_keys = c->nl != c->nl_ext ? c->d_out_keys_ext : c->d_out_keys;
     out->d_counts = c->d_out_counts;
     out->d_left = c->d_out_left;
     out->d_right = c->d_out_right;
@@ -1739,7 +1771,7 @@ extern "C" int kc_copy_results(kc_ctx *c, uint64_t *keys, uint16_t *counts, uint
   HIPCHK(hipSetDevice(c->cfg.device));
   const uint64_t n = c->out_n;
   if (!n) return KC_OK;
-  if (keys) HIPCHK(hipMemcpy(keys, c->d_out_keys, n * c->nl * 8, hipMemcpyDeviceToHost));
+  if (keys) HIPCHK(hipMemcpy(keys, c->nl != c->nl_ext ? c->d_out_keys_ext : c->d_out_keys, n * c->nl_ext * 8, hipMemcpyDeviceToHost));
   if (counts) HIPCHK(hipMemcpy(counts, c->d_out_counts, n * 2, hipMemcpyDeviceToHost));
   if (left) HIPCHK(hipMemcpy(left, c->d_out_left, n, hipMemcpyDeviceToHost));
   if (right) HIPCHK(hipMemcpy(right, c->d_out_right, n, hipMemcpyDeviceToHost));
@@ -1779,6 +1811,23 @@ static int bk_dump(kc_ctx *c, uint64_t **dk, uint16_t **dc, uint16_t **de, uint6
   return bk_move_flagged(c);
 }
 
+// n keys from a device array of the library's width to a host array of the reference's width
+static int keys_to_host(kc_ctx *c, uint64_t *h_dst, const uint64_t *d_src, uint64_t n) {
+  if (!n) return KC_OK;
+  if (c->nl == c->nl_ext) {
+    HIPCHK(hipMemcpy(h_dst, d_src, n * c->nl * 8, hipMemcpyDeviceToHost));
+    return KC_OK;
+  }
+  uint64_t *tmp = nullptr;
+  HIPCHK(hipMalloc((void **)&tmp, n * c->nl_ext * 8));
+  hipLaunchKernelGGL(kc_rewidth_keys_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, c->stream, d_src, tmp, n, c->nl, c->nl_ext);
+  hipError_t e = hipStreamSynchronize(c->stream);
+  if (e == hipSuccess) e = hipMemcpy(h_dst, tmp, n * c->nl_ext * 8, hipMemcpyDeviceToHost);
+  (void)hipFree(tmp);
+  if (e != hipSuccess) return hip_fail(e, "keys_to_host", __LINE__);
+  return KC_OK;
+}
+
 extern "C" int kc_dump_table(kc_ctx *c, uint64_t *keys, uint16_t *counts, uint16_t *exts, uint64_t *n_out) {
   if (!c || !n_out) return KC_ERR_INVALID_ARG;
   HIPCHK(hipSetDevice(c->cfg.device));
@@ -1804,7 +1853,8 @@ extern "C" int kc_dump_table(kc_ctx *c, uint64_t *keys, uint16_t *counts, uint16
     return KC_OK;
   }
   if (nreg) {
-    HIPCHK(hipMemcpy(keys, rk, nreg * c->nl * 8, hipMemcpyDeviceToHost));
+    rc = keys_to_host(c, keys, rk, nreg);
+    if (rc) return rc;
     HIPCHK(hipMemcpy(counts, rc16, nreg * 2, hipMemcpyDeviceToHost));
     HIPCHK(hipMemcpy(exts, re, nreg * 16, hipMemcpyDeviceToHost));
     (void)hipFree(rk);
@@ -1829,7 +1879,8 @@ extern "C" int kc_dump_table(kc_ctx *c, uint64_t *keys, uint16_t *counts, uint16
     c->num_gpu_calls++;
     HIPCHK(hipGetLastError());
     HIPCHK(hipStreamSynchronize(c->stream));
-    HIPCHK(hipMemcpy(keys + nreg * c->nl, dk, ntab * c->nl * 8, hipMemcpyDeviceToHost));
+    rc = keys_to_host(c, keys + nreg * c->nl_ext, dk, ntab);
+    if (rc) return rc;
     HIPCHK(hipMemcpy(counts + nreg, dc, ntab * 2, hipMemcpyDeviceToHost));
     HIPCHK(hipMemcpy(exts + nreg * 8, de, ntab * 16, hipMemcpyDeviceToHost));
     (void)hipFree(dk);
@@ -1911,13 +1962,20 @@ extern "C" int kc_lookup(kc_ctx *c, const uint64_t *queries, uint64_t nq, int on
   uint64_t *sq = nullptr;
   uint16_t *dc = counts;
   uint8_t *dl = left, *dr = right;
+  uint64_t *wq = nullptr;  // the queries at the library's width, where that differs from the caller's
   if (!on_device && nq) {
-    HIPCHK(hipMalloc((void **)&sq, nq * c->nl * 8 + nq * 4));
-    HIPCHK(hipMemcpyAsync(sq, queries, nq * c->nl * 8, hipMemcpyHostToDevice, c->stream));
+    HIPCHK(hipMalloc((void **)&sq, nq * c->nl_ext * 8 + nq * 4));
+    HIPCHK(hipMemcpyAsync(sq, queries, nq * c->nl_ext * 8, hipMemcpyHostToDevice, c->stream));
     dq = sq;
-    dc = (uint16_t *)(sq + nq * c->nl);
+    dc = (uint16_t *)(sq + nq * c->nl_ext);
     dl = (uint8_t *)(dc + nq);
     dr = dl + nq;
+  }
+  if (c->nl != c->nl_ext && nq) {
+    HIPCHK(hipMalloc((void **)&wq, nq * c->nl * 8));
+    hipLaunchKernelGGL(kc_rewidth_keys_kernel, dim3((unsigned)((nq + 255) / 256)), dim3(256), 0, c->stream, dq, wq, nq, c->nl_ext, c->nl);
+    HIPCHK(hipGetLastError());
+    dq = wq;
   }
   int rc;
   switch (c->nl) {
@@ -1931,6 +1989,10 @@ extern "C" int kc_lookup(kc_ctx *c, const uint64_t *queries, uint64_t nq, int on
     HIPCHK(hipMemcpy(counts, dc, nq * 2, hipMemcpyDeviceToHost));
     if (left) HIPCHK(hipMemcpy(left, dl, nq, hipMemcpyDeviceToHost));
     if (right) HIPCHK(hipMemcpy(right, dr, nq, hipMemcpyDeviceToHost));
+  }
+  if (wq) {
+    (void)hipStreamSynchronize(c->stream);
+    (void)hipFree(wq);
   }
   if (sq) (void)hipFree(sq);
   return rc;

@@ -87,7 +87,8 @@ class ShardExchange {
   }
 
  public:
-  // ctx: this rank's context (created with the same rank_me / rank_n as `comm`); seg_capacity: records one block may
+  // ctx: this rank's context (created with the same rank_me / rank_n as `comm`); num_longs: words of a record on the
+  // wire, kc_record_longs(k); seg_capacity: records one block may
   // send to one shard (a block of R reads of length L needs about R * (L - k - 1) / rank_n * 1.25);
   // compute_stream: the stream the context's kernels should run on, NULL = a stream of this object's own.
   ShardExchange(kc_ctx *ctx_, ncclComm_t comm_, int rank_me, int rank_n, int num_longs, uint64_t seg_capacity,

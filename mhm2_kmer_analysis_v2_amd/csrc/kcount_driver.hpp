@@ -85,7 +85,8 @@ class ParseAndPackDriver {
   kc_ctx *ctx = nullptr;
   int rank_n;
   int kmer_len;
-  int num_longs;
+  int num_longs;   // of a k-mer (the reference's N_LONGS)
+  int rec_longs;   // of a record on the shard wire (kc_record_longs)
   bool records_mode;
   uint64_t *d_records = nullptr;  // rank_n segments of seg_capacity records
   uint64_t seg_capacity = 0;
@@ -106,7 +107,8 @@ class ParseAndPackDriver {
   // supermers (the native flow; ownership is then a hash of the k-mer, F3 in SURVEY.md).
   ParseAndPackDriver(int upcxx_rank_me, int upcxx_rank_n, int qual_offset, int kmer_len, int num_kmer_longs, int minimizer_len,
                      double &init_time, bool records_mode = false, int device = 0)
-      : rank_n(upcxx_rank_n), kmer_len(kmer_len), num_longs(num_kmer_longs), records_mode(records_mode), h_counts(upcxx_rank_n, 0) {
+      : rank_n(upcxx_rank_n), kmer_len(kmer_len), num_longs(num_kmer_longs), rec_longs(kc_record_longs(kmer_len)),
+        records_mode(records_mode), h_counts(upcxx_rank_n, 0) {
     StopWatch sw;
     kc_config cfg{};
     cfg.kmer_len = kmer_len;
@@ -134,7 +136,7 @@ class ParseAndPackDriver {
 
   // parse_and_pack.cpp:281-319.  seqs: case-masked reads joined by '_'.  false if empty, shorter than k or too long.
   // Wire mode: fills `supermers`.  Records mode: counts()[t] records for target t start at
-  // records() + t * segment_capacity() * num_longs.
+  // records() + t * segment_capacity() * record_longs().
   bool process_seq_block(const std::string &seqs, unsigned int &num_valid_kmers) {
     StopWatch sw;
     num_valid_kmers = 0;
@@ -156,7 +158,7 @@ class ParseAndPackDriver {
     if (seqs.length() > seg_capacity) {
       if (d_records) (void)hipFree(d_records);
       seg_capacity = seqs.length();
-      if (hipMalloc((void **)&d_records, seg_capacity * rank_n * num_longs * 8) != hipSuccess) die("hipMalloc(records)", KC_ERR_OUT_OF_MEMORY);
+      if (hipMalloc((void **)&d_records, seg_capacity * rank_n * rec_longs * 8) != hipSuccess) die("hipMalloc(records)", KC_ERR_OUT_OF_MEMORY);
     }
     StopWatch kw;
     check(kc_extract_partition_seq_block(ctx, seqs.data(), seqs.size(), 0, d_records, seg_capacity, h_counts.data()),
@@ -179,6 +181,7 @@ class ParseAndPackDriver {
 
   const uint64_t *records() const { return d_records; }  // device pointer
   uint64_t segment_capacity() const { return seg_capacity; }
+  int record_longs() const { return rec_longs; }
   const std::vector<uint64_t> &counts() const { return h_counts; }
 };
 

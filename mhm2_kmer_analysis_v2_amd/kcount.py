@@ -65,7 +65,8 @@ class KmerCounter:
         if not self._h:
             raise _lib.KcError(st.value, "kc_create")
         self.k = kmer_len
-        self.nl = L.kc_num_longs(kmer_len)
+        self.nl = L.kc_num_longs(kmer_len)          # words of a k-mer in results, dumps and lookups (the reference's)
+        self.rec_nl = L.kc_record_longs(kmer_len)   # words of a record on the shard wire (extract_partition / insert_records)
         self.rank_me, self.rank_n = rank_me, rank_n
         self._tuning = tuning
         if tuning:
@@ -108,6 +109,7 @@ class KmerCounter:
         if new_kmer_len:
             self.k = new_kmer_len
             self.nl = lib().kc_num_longs(new_kmer_len)
+            self.rec_nl = lib().kc_record_longs(new_kmer_len)
 
     def submit_reads(self, bases, quals, offsets, nreads=None):
         pb, dev = _ptr(bases)

@@ -36,7 +36,7 @@ int main(int argc, char **argv) {
     unsigned nvalid = 0;
     if (!pnp.process_seq_block(block, nvalid)) return 2;
     for (int r = 0; r < R; r++)
-      ht[r]->insert_records(pnp.records() + (size_t)r * pnp.segment_capacity() * kc_num_longs(k), pnp.counts()[r]);
+      ht[r]->insert_records(pnp.records() + (size_t)r * pnp.segment_capacity() * pnp.record_longs(), pnp.counts()[r]);
   } else if (mode == "wire") {
     // The reference's own flow, step for step as its host file drives the two drivers (process_block,
     // src/kcount/kcount_gpu.cpp:110-165): supermers and the packed block from the sender driver, every supermer's bytes

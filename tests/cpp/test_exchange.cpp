@@ -80,7 +80,7 @@ int main(int argc, char **argv) {
     nblocks = all;
     (void)hipFree(d);
   }
-  ShardExchange ex(ctx, comm, rank, nranks, nl, per_block * 400 + 64);
+  ShardExchange ex(ctx, comm, rank, nranks, kc_record_longs(k), per_block * 400 + 64);
   if (ex.init() != KC_OK) {
     std::fprintf(stderr, "init: %s\n", ex.last_error());
     return 4;

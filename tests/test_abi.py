@@ -39,12 +39,13 @@ def test_version_and_error_strings():
 def test_num_longs_matches_reference_rule():
     L = pkg.lib()
     assert [L.kc_num_longs(k) for k in (21, 31, 32, 33, 63, 64, 77, 99)] == [1, 1, 2, 2, 2, 3, 3, 4]
+    assert [L.kc_record_longs(k) for k in (21, 29, 30, 31, 32, 62, 63, 95, 125)] == [1, 1, 2, 2, 2, 3, 3, 4, 4]
 
 
 def test_create_argument_checks_need_no_gpu():
     L = pkg.lib()
     st = C.c_int(0)
-    for k, want in ((2, -2), (128, -2), (30, -2), (31, -2), (62, -2)):
+    for k, want in ((2, -2), (128, -2), (126, -2), (127, -2)):  # 126, 127: a fifth record word would be needed
         cfg = _lib.kc_config(kmer_len=k, qual_offset=33, dmin_thres=2, device=0, rank_me=0, rank_n=1)
         assert not L.kc_create(C.byref(cfg), C.byref(st)) and st.value == want, k
     cfg = _lib.kc_config(kmer_len=21, qual_offset=33, dmin_thres=2, device=0, rank_me=2, rank_n=2)

@@ -38,7 +38,7 @@ def test_sharded_analysis_over_nccl(nccl_world1, k, tuning):
     wst = o.stats()
     o.close()
     dev = torch.device("cuda", 0)
-    nl = pkg.lib().kc_num_longs(k)
+    nl = pkg.lib().kc_record_longs(k)
     db = torch.from_numpy(b).to(dev)
     dq = torch.from_numpy(q).to(dev)
     do = torch.from_numpy(offs.astype(np.int64)).to(dev)

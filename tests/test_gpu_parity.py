@@ -45,7 +45,7 @@ PATHS = {
 
 
 @pytest.mark.parametrize("path", list(PATHS))
-@pytest.mark.parametrize("k", [13, 17, 21, 23, 29, 33, 51, 55, 64, 77, 99])
+@pytest.mark.parametrize("k", [13, 17, 21, 23, 29, 30, 31, 33, 51, 55, 62, 63, 64, 77, 95, 99, 125])  # 30/31 mod 32: extension word
 def test_random_reads_match_oracle(k, path):
     rng = np.random.default_rng(100 + k)
     reads, quals = random_reads(rng, 1500, min_len=max(3, k - 5), max_len=k + 130, genome_len=3000)
@@ -135,8 +135,8 @@ def test_sharded_flow_on_one_gpu():
     """kc_extract_partition -> (exchange) -> kc_insert_records with three shards living on one
     device: the union of the shards' results is the oracle's set and no k-mer has two owners."""
     import torch
-    for k in (21, 51):
-        nl = pkg.lib().kc_num_longs(k)
+    for k in (21, 31, 51):
+        nl = pkg.lib().kc_record_longs(k)  # words of a record on the wire (31: one more than the k-mer's)
         rng = np.random.default_rng(10 + k)
         reads, quals = random_reads(rng, 1000, min_len=30, max_len=150, genome_len=2500)
         b, q, offs = arrays(reads, quals)
@@ -157,7 +157,7 @@ def test_sharded_flow_on_one_gpu():
                 shards[d].flush()
         parts = [s.sorted_results() for s in shards]
         keys = np.concatenate([p[0] for p in parts])
-        order = np.lexsort([keys[:, j] for j in range(nl - 1, -1, -1)])
+        order = np.lexsort([keys[:, j] for j in range(keys.shape[1] - 1, -1, -1)])
         got = tuple(np.concatenate([p[i] for p in parts])[order] for i in range(4))
         assert_same(got, want)
         L = pkg.lib()
@@ -462,7 +462,7 @@ def test_reference_owner_mode_bins_like_get_kmer_target_rank(k):
         s.close()
 
 
-@pytest.mark.parametrize("k", [21, 51])
+@pytest.mark.parametrize("k", [21, 31, 51, 63])
 def test_lookup_over_results(k):
     """kc_lookup = KmerDHT::get_kmer_count in bulk: every result is found with its count and extensions from either
     strand; purged and never-seen k-mers come back with count 0."""

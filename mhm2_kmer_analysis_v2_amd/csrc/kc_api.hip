@@ -1551,7 +1551,7 @@ static int bk_build_regions(kc_ctx *c) {
 template <int NL, bool DUMP>
 static int bk_count_t(kc_ctx *c, const OutBufs &ob) {
   auto kern = use_cp<NL>(c) ? kc_count_kernel<NL, DUMP, NL == 1> : kc_count_kernel<NL, DUMP, false>;
-  const size_t lds = CountLDS<NL>::bytes(c->gm.S);
+  const size_t lds = CountLDS<NL>::bytes(c->gm.S, use_cp<NL>(c));
   int rc = set_dyn_lds(kern, lds);
   if (rc) return rc;
   const uint64_t R = (uint64_t)c->gm.P1 * c->gm.P2;

@@ -1024,47 +1024,63 @@ __global__ __launch_bounds__(TPB) void kc_ovf1_drain_kernel(Geom gm, BucketBufs 
 constexpr uint32_t CHAIN_LDS = 512;  // longest region chain (L2MAX) the count kernel can stage
 
 // LDS image of one region, structure-of-arrays so that neighbouring slots sit in neighbouring banks.
-// The table size is a power of two (cheap wrap, low load: the probe loop runs in lock step, so a wave pays for
-// its longest probe).  The eight extension counters are packed two per word (16 bits each): a half can only
-// overflow when the k-mer itself was seen more than 65535 times, and then the whole region is handed to the
-// global table (flag 2), whose counters are 32 bits wide.
+// The table size is a power of two (cheap wrap, low load: a lane's probe sequence is as long as the run of occupied
+// slots it starts in).  Ten 16-bit counters per entry in five words: the four extensions of either side and, per side,
+// the occurrences that came WITHOUT a usable extension -- so that the k-mer's own count is the sum of one side's five
+// and need not be counted separately (two LDS adds per occurrence instead of three).  No half can overflow in a region
+// of at most 65535 records; a larger one (a k-mer seen more often than that, S6) is handed whole to the global table
+// (flag 2), whose counters are 32 bits wide.
 template <int NL>
 struct CountLDS {  // header at the start of the dynamic LDS; the arrays follow, strided by the region's S
   static constexpr uint32_t SMAX = NL <= 2 ? 4096 : 2048;
+  static constexpr uint32_t QSLOTS = 128;  // pending probes a wave can park (compact records: the probe queue)
   uint32_t chain[CHAIN_LDS];  // the region's chunk ids
   uint32_t nout, nocc, fail, gbase_lo, gbase_hi;
   uint32_t gbase2_lo, gbase2_hi, split;  // ranks >= split continue at gbase2 (a region may straddle two blocks)
   unsigned long long sum;
   static constexpr size_t header_bytes() { return (sizeof(CountLDS<NL>) + 15) & ~size_t(15); }
-  static constexpr size_t bytes(uint32_t S) { return header_bytes() + (size_t)S * (8 * NL + 20 + 2); }
+  // cp: compact records, 32-bit keys and one probe queue per wave
+  static constexpr size_t bytes(uint32_t S, bool cp) {
+    return header_bytes() + (size_t)S * ((cp ? 4 : 8 * NL) + 20 + 2) + (cp ? (size_t)(WGB / 64) * QSLOTS * 8 : 0) + 16;
+  }
 };
 
-// the arrays of one region table: word w of slot s at keys[w*S + s] (the LAST word is the claim word);
-// ext[q*S + s]: q = 0 left A|C<<16, 1 left G|T<<16, 2 right A|C<<16, 3 right G|T<<16
+// the arrays of one region table: word w of slot s at keys[w*S + s] (the LAST word is the claim word; compact
+// records: one 32-bit key per slot);
+// ext[q*S + s]: q = 0 left A|C<<16, 1 left G|T<<16, 2 right A|C<<16, 3 right G|T<<16, 4 left none | right none<<16
+// (after the vote an entry's word 4 holds its count, extensions and rank for the write-out)
 // occ lists the occupied slots in claim order, so that the vote, the write-out and the clean-up of a region visit
 // only its entries (dense lanes) instead of scanning every slot
 struct CountTab {
   uint64_t *keys;
-  uint32_t *cnt;
   uint32_t *ext;
   uint16_t *occ;
-  uint32_t S;
+  uint64_t *queue;  // compact records: [WGB/64][QSLOTS] parked probes
+  uint32_t S, lgS;
 };
 
-template <int NL>
+template <int NL, bool CP>
 __device__ __forceinline__ CountTab count_tab(uint8_t *smem, uint32_t S) {
   CountTab t;
-  t.keys = reinterpret_cast<uint64_t *>(smem + CountLDS<NL>::header_bytes());
-  t.cnt = reinterpret_cast<uint32_t *>(t.keys + (size_t)NL * S);
-  t.ext = t.cnt + S;
-  t.occ = reinterpret_cast<uint16_t *>(t.ext + 4 * (size_t)S);
+  uint8_t *p = smem + CountLDS<NL>::header_bytes();
+  t.queue = reinterpret_cast<uint64_t *>(p);
+  if (CP) p += (size_t)(WGB / 64) * CountLDS<NL>::QSLOTS * 8;
+  t.keys = reinterpret_cast<uint64_t *>(p);
+  p += (size_t)S * (CP ? 4 : 8 * NL);
+  t.ext = reinterpret_cast<uint32_t *>(p);
+  t.occ = reinterpret_cast<uint16_t *>(t.ext + 5 * (size_t)S);
   t.S = S;
+  t.lgS = 31u - (uint32_t)__clz(S);
   return t;
 }
 
-// bump the counter of extension code e (0-3) on side (0 left, 1 right)
-__device__ __forceinline__ void ext_bump(uint32_t *ext, uint32_t SM, uint32_t s, uint32_t side, uint32_t e) {
-  atomicAdd(&ext[(2 * side + (e >> 1)) * SM + s], 1u << (16 * (e & 1u)));
+// one occurrence with extension codes le, re (0-3 = ACGT, >= 4 = none) at slot s: S5/S6 in two LDS adds
+__device__ __forceinline__ void ext_count(const CountTab &tb, uint32_t s, uint32_t le, uint32_t re) {
+  const bool nl = (le & 4u) != 0, nr = (re & 4u) != 0;
+  const uint32_t wl = nl ? 4u : (le >> 1), wr = nr ? 4u : 2u + (re >> 1);
+  const uint32_t il = nl ? 1u : 1u << ((le & 1u) << 4), ir = nr ? 0x10000u : 1u << ((re & 1u) << 4);
+  atomicAdd(&tb.ext[(wl << tb.lgS) + s], il);
+  atomicAdd(&tb.ext[(wr << tb.lgS) + s], ir);
 }
 __device__ __forceinline__ uint32_t ext_get(const uint32_t *ext, uint32_t SM, uint32_t s, uint32_t side, uint32_t e) {
   return (ext[(2 * side + (e >> 1)) * SM + s] >> (16 * (e & 1u))) & 0xFFFFu;
@@ -1128,7 +1144,9 @@ __device__ __forceinline__ uint32_t lds_probe1(unsigned long long *claim, uint32
 }
 
 // The same probe on 32-bit keys (compact records): a 32-bit LDS compare-and-swap runs at about three times the rate
-// of a 64-bit one.  EMPTY is all ones, which no key is (a key has at most 26 bits).
+// of a 64-bit one.  EMPTY is all ones, which no key is (a key has at most 26 bits).  (Reading the slot first and
+// claiming only an empty one -- reads of one address share an access, compare-and-swaps of one address queue -- was
+// measured 6 % slower: the extra dependent LDS trip of the new keys costs more than the queueing.)
 __device__ __forceinline__ uint32_t lds_probe32(uint32_t *claim, uint32_t Sm1, uint32_t key, uint32_t slot, uint32_t valid, uint32_t &failed) {
   uint32_t act = valid, trips = 0;
   do {
@@ -1192,7 +1210,7 @@ __global__ __launch_bounds__(WGB, 8) void kc_count_kernel(Geom gm, BucketBufs bb
   CountLDS<NL> &T = *reinterpret_cast<CountLDS<NL> *>(smem);
   const int tid = threadIdx.x;
   const uint32_t S = gm.S, SM = gm.S;
-  const CountTab tb = count_tab<NL>(smem, S);
+  const CountTab tb = count_tab<NL, CP>(smem, S);
   const size_t R = (size_t)gm.P1 * gm.P2;
   // diagnostic builds only (-DKC_STAMPS): thread 0 accumulates the cycles between the phase boundaries of every region
   // into cb[8..]; the shipped build has no stamp code at all
@@ -1217,9 +1235,8 @@ __global__ __launch_bounds__(WGB, 8) void kc_count_kernel(Geom gm, BucketBufs bb
 #pragma unroll
       for (int w = 0; w < NL; w++) tb.keys[w * SM + s] = KEY_EMPTY;
     }
-    tb.cnt[s] = 0;
 #pragma unroll
-    for (int e = 0; e < 4; e++) tb.ext[e * SM + s] = 0;
+    for (int e = 0; e < 5; e++) tb.ext[e * SM + s] = 0;
   };
   for (uint32_t s = tid; s < S; s += WGB) reset_slot(s);
   if (tid == 0) T.nocc = 0;
@@ -1229,6 +1246,10 @@ __global__ __launch_bounds__(WGB, 8) void kc_count_kernel(Geom gm, BucketBufs bb
   for (size_t r = blockIdx.x; r < R; r += gridDim.x) {
     const uint32_t n = bb.cnt2[r];
     if (n == 0 || bb.flag[r]) continue;  // uniform across the workgroup
+    if (n > KC_COUNT_MAX) {              // a 16-bit counter could overflow: the global table takes the region
+      if (tid == 0) bb.flag[r] = 2;
+      continue;
+    }
 #ifdef KC_STAMPS
     if (stamp) tprev = __builtin_amdgcn_s_memtime();
 #endif
@@ -1281,11 +1302,7 @@ __global__ __launch_bounds__(WGB, 8) void kc_count_kernel(Geom gm, BucketBufs bb
           const uint32_t le = r0 & 7u, re = (r0 >> 3) & 7u;
           // only lanes that hold a record touch the counters: the idle lanes of a wave all re-read record 0, and 64
           // atomic adds of zero to one LDS word are serialised
-          if (v) {
-            atomicAdd(&tb.cnt[s], 1u);
-            atomicAdd(&tb.ext[((le >> 1) & 1u) * SM + s], (1u << ((le & 1u) << 4)) & (((le >> 2) & 1u) - 1u));
-            atomicAdd(&tb.ext[(2u + ((re >> 1) & 1u)) * SM + s], (1u << ((re & 1u) << 4)) & (((re >> 2) & 1u) - 1u));
-          }
+          if (v) ext_count(tb, s, le, re);
         }
         if (failed) T.fail = 1;
       } else if constexpr (NL == 1) {
@@ -1300,11 +1317,7 @@ __global__ __launch_bounds__(WGB, 8) void kc_count_kernel(Geom gm, BucketBufs bb
           // S5/S6: the k-mer itself, and each extension that is an ACGT base (codes 0-3; 4 = none adds 0).  Only
           // lanes that hold a record touch the counters (see the compact path above)
           const uint32_t le = (uint32_t)r0 & 7u, re = ((uint32_t)r0 >> 3) & 7u;
-          if (v) {
-            atomicAdd(&tb.cnt[s], 1u);
-            atomicAdd(&tb.ext[((le >> 1) & 1u) * SM + s], (1u << ((le & 1u) << 4)) & (((le >> 2) & 1u) - 1u));
-            atomicAdd(&tb.ext[(2u + ((re >> 1) & 1u)) * SM + s], (1u << ((re & 1u) << 4)) & (((re >> 2) & 1u) - 1u));
-          }
+          if (v) ext_count(tb, s, le, re);
         }
         if (failed) T.fail = 1;
       } else {
@@ -1319,11 +1332,7 @@ __global__ __launch_bounds__(WGB, 8) void kc_count_kernel(Geom gm, BucketBufs bb
           const uint32_t le = (uint32_t)(rec[j][NL - 1] & 7u), re = (uint32_t)((rec[j][NL - 1] >> 3) & 7u);
           key[NL - 1] &= ~KC_EXT_MASK;
           const uint32_t s = lds_probeN<NL>(tb, key, hash_slot(kc_hash<NL>(key), S), v, failed);
-          if (v && !(failed & 1u)) {
-            atomicAdd(&tb.cnt[s], 1u);
-            if (le < 4u) ext_bump(tb.ext, SM, s, 0, le);
-            if (re < 4u) ext_bump(tb.ext, SM, s, 1, re);
-          }
+          if (v && !(failed & 1u)) ext_count(tb, s, le, re);
         }
         if (failed) T.fail = 1;
       }
@@ -1334,7 +1343,9 @@ __global__ __launch_bounds__(WGB, 8) void kc_count_kernel(Geom gm, BucketBufs bb
     // clean-up then visit only the region's entries, with every lane busy
     for (uint32_t s0 = 0; s0 < S; s0 += WGB) {
       const uint32_t s = s0 + tid;
-      occ_push(&T.nocc, tb.occ, s < S && tb.cnt[s] != 0u, s);
+      bool taken = false;
+      if (s < S) taken = CP ? keys32[s] != 0xFFFFFFFFu : tb.keys[(NL - 1) * SM + s] != KEY_EMPTY;
+      occ_push(&T.nocc, tb.occ, taken, s);
     }
     __syncthreads();
     KC_STAMP(2)  // list the entries
@@ -1347,19 +1358,20 @@ __global__ __launch_bounds__(WGB, 8) void kc_count_kernel(Geom gm, BucketBufs bb
       const uint32_t e = e0 + tid;
       const bool live = e < nocc;
       const uint32_t s = live ? tb.occ[e] : 0u;
-      const uint32_t count = live ? tb.cnt[s] : 0u;
-      if (count > KC_COUNT_MAX) T.fail = 1;
+      uint32_t w[5] = {0, 0, 0, 0, 0};
+      if (live) {
+#pragma unroll
+        for (int x = 0; x < 5; x++) w[x] = tb.ext[x * SM + s];
+      }
+      // the k-mer's count: every occurrence bumped exactly one of the left side's five counters (<= 65535: n is)
+      const uint32_t count = (w[0] & 0xFFFFu) + (w[0] >> 16) + (w[1] & 0xFFFFu) + (w[1] >> 16) + (w[4] & 0xFFFFu);
       bool keep = false;
       uint32_t l = 0, rr = 0;
       if (DUMP) {
         keep = live;
       } else if (count >= 2) {
-        uint32_t lc[4], rc[4];
-#pragma unroll
-        for (int x = 0; x < 4; x++) {
-          lc[x] = ext_get(tb.ext, SM, s, 0, x);
-          rc[x] = ext_get(tb.ext, SM, s, 1, x);
-        }
+        const uint32_t lc[4] = {w[0] & 0xFFFFu, w[0] >> 16, w[1] & 0xFFFFu, w[1] >> 16};
+        const uint32_t rc[4] = {w[2] & 0xFFFFu, w[2] >> 16, w[3] & 0xFFFFu, w[3] >> 16};
         l = vote_ext(lc, count, dmin_thres);
         rr = vote_ext(rc, count, dmin_thres);
         keep = l < 4u && rr < 4u;
@@ -1375,10 +1387,10 @@ __global__ __launch_bounds__(WGB, 8) void kc_count_kernel(Geom gm, BucketBufs bb
         if (lane_id() == 0 && !DUMP) atomicAdd(&T.sum, (unsigned long long)wsum);
         if (keep) {
           const uint32_t rank = base + (uint32_t)__popcll(m & ((1ULL << lane_id()) - 1ULL));
-          tb.cnt[s] = DUMP ? (count | (rank << 20)) : ((count & 0xFFFFu) | (l << 16) | (rr << 18) | (rank << 20));
+          tb.ext[4 * SM + s] = DUMP ? (count | (rank << 20)) : ((count & 0xFFFFu) | (l << 16) | (rr << 18) | (rank << 20));
         }
       }
-      if (live && !keep) tb.cnt[s] = ~0u;
+      if (live && !keep) tb.ext[4 * SM + s] = ~0u;
     }
     __syncthreads();
     if (T.fail) {  // more distinct k-mers than slots, or a saturated k-mer: the whole region goes to the global table instead
@@ -1427,7 +1439,7 @@ __global__ __launch_bounds__(WGB, 8) void kc_count_kernel(Geom gm, BucketBufs bb
     const uint32_t split = T.split;
     for (uint32_t e = tid; e < nocc; e += WGB) {
       const uint32_t s = tb.occ[e];
-      const uint32_t p = tb.cnt[s];
+      const uint32_t p = tb.ext[4 * SM + s];
       if (p != ~0u) {
         const uint32_t rank = p >> 20;
         const uint64_t o = rank < split ? gbase + rank : gbase2 + (rank - split);

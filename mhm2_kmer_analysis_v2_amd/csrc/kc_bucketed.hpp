@@ -1033,16 +1033,13 @@ constexpr uint32_t CHAIN_LDS = 512;  // longest region chain (L2MAX) the count k
 template <int NL>
 struct CountLDS {  // header at the start of the dynamic LDS; the arrays follow, strided by the region's S
   static constexpr uint32_t SMAX = NL <= 2 ? 4096 : 2048;
-  static constexpr uint32_t QSLOTS = 128;  // pending probes a wave can park (compact records: the probe queue)
   uint32_t chain[CHAIN_LDS];  // the region's chunk ids
   uint32_t nout, nocc, fail, gbase_lo, gbase_hi;
   uint32_t gbase2_lo, gbase2_hi, split;  // ranks >= split continue at gbase2 (a region may straddle two blocks)
   unsigned long long sum;
   static constexpr size_t header_bytes() { return (sizeof(CountLDS<NL>) + 15) & ~size_t(15); }
-  // cp: compact records, 32-bit keys and one probe queue per wave
-  static constexpr size_t bytes(uint32_t S, bool cp) {
-    return header_bytes() + (size_t)S * ((cp ? 4 : 8 * NL) + 20 + 2) + (cp ? (size_t)(WGB / 64) * QSLOTS * 8 : 0) + 16;
-  }
+  // cp: compact records, 32-bit keys
+  static constexpr size_t bytes(uint32_t S, bool cp) { return header_bytes() + (size_t)S * ((cp ? 4 : 8 * NL) + 20 + 2) + 16; }
 };
 
 // the arrays of one region table: word w of slot s at keys[w*S + s] (the LAST word is the claim word; compact
@@ -1055,7 +1052,6 @@ struct CountTab {
   uint64_t *keys;
   uint32_t *ext;
   uint16_t *occ;
-  uint64_t *queue;  // compact records: [WGB/64][QSLOTS] parked probes
   uint32_t S, lgS;
 };
 
@@ -1063,8 +1059,6 @@ template <int NL, bool CP>
 __device__ __forceinline__ CountTab count_tab(uint8_t *smem, uint32_t S) {
   CountTab t;
   uint8_t *p = smem + CountLDS<NL>::header_bytes();
-  t.queue = reinterpret_cast<uint64_t *>(p);
-  if (CP) p += (size_t)(WGB / 64) * CountLDS<NL>::QSLOTS * 8;
   t.keys = reinterpret_cast<uint64_t *>(p);
   p += (size_t)S * (CP ? 4 : 8 * NL);
   t.ext = reinterpret_cast<uint32_t *>(p);

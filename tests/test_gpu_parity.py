@@ -39,6 +39,7 @@ PATHS = {
     "bucketed-small": dict(writers=3, p1=4, p2=8, slots=512),
     "bucketed-odd": dict(writers=5, p1=7, p2=13, slots=256),
     "compact": dict(writers=3, p1=256, p2=256, slots=512),
+    "compact-short": dict(writers=5, p1=1024, p2=512, slots=256),  # the mix fits 32 bits below the bucket up to k = 21: kc_compact.hpp
     "wide": dict(mode=2, writers=3, p1=256, p2=256, slots=512),
     "table": dict(mode=1),
 }

@@ -161,6 +161,21 @@ int kc_submit_reads(kc_ctx *ctx, const uint8_t *bases, const uint8_t *quals, con
 int kc_submit_packed_reads(kc_ctx *ctx, const uint8_t *packed, const uint64_t *offsets, uint64_t nreads, int on_device);
 
 /*
+ * FASTQ text -> the read cache's packed bytes, on the host (no context, no GPU): the unpaired pass of
+ * FastqReader::get_next_fq_record (src/fastq.cpp:1028-1140: four lines per record, '@' name, sequence, '+' line,
+ * qualities of the sequence's length; trailing white space and CR stripped) followed by PackedRead's constructor
+ * (src/packed_reads.cpp:99-126: ACGT 0-3, N and the IUPAC codes 4, quality min(q - qual_offset, 31) << 3).  The reads
+ * are appended to packed[0..packed_capacity) with offsets[r] .. offsets[r+1] (offsets[0] = 0, reads_capacity + 1 entries),
+ * ready for kc_submit_packed_reads.  *nreads / *nbytes receive the totals of the whole text even when the arrays are too
+ * small (KC_ERR_CAPACITY: call again with that much room; call with NULL arrays to size).  KC_ERR_BAD_BASE: a character
+ * the reference DIEs on; KC_ERR_INVALID_ARG: a malformed record (kc_last_error names the line).
+ * The reference's dummy mate of an unpaired read (the one-base read "N", src/merge_reads.cpp:372-377) holds no k-mer
+ * and is not produced.
+ */
+int kc_fastq_to_packed(const char *text, uint64_t len, int qual_offset, uint8_t *packed, uint64_t packed_capacity, uint64_t *offsets,
+                       uint64_t reads_capacity, uint64_t *nreads, uint64_t *nbytes);
+
+/*
  * ParseAndPackGPUDriver::process_seq_block input format
  * (src/kcount/kcount_gpu.cpp:167-180, parse_and_pack.cpp:281-319): reads already
  * case-masked (lowercase = low quality) and joined by '_'.

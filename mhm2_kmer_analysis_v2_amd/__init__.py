@@ -7,4 +7,4 @@ reference's analyze_kmers flow (src/kcount/kcount.cpp:142-161).  There is no CPU
 fallback: without the built library or without a GPU every call fails loudly.
 """
 from ._lib import KcError, lib, lib_path  # noqa: F401
-from .kcount import KmerCounter, analyze_kmers, synth_params, synth_reads_host  # noqa: F401
+from .kcount import KmerCounter, analyze_kmers, fastq_to_packed, synth_params, synth_reads_host  # noqa: F401

@@ -70,6 +70,8 @@ SYMBOLS = {
     "kc_reset": (C.c_int, [C.c_void_p, C.c_int]),
     "kc_submit_reads": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_uint64, C.c_int]),
     "kc_submit_packed_reads": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_uint64, C.c_int]),
+    "kc_fastq_to_packed": (C.c_int, [C.c_char_p, C.c_uint64, C.c_int, C.c_void_p, C.c_uint64, C.c_void_p, C.c_uint64, C.POINTER(C.c_uint64),
+                                      C.POINTER(C.c_uint64)]),
     "kc_submit_seq_block": (C.c_int, [C.c_void_p, C.c_void_p, C.c_uint64, C.c_int]),
     "kc_extract_partition": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_uint64, C.c_int, C.c_void_p,
                                        C.c_uint64, C.c_void_p]),

@@ -587,6 +587,9 @@ static int bk_init(kc_ctx *c) {
   HIPCHK(hipMemsetAsync(b.cnt2, 0, (size_t)R * 4, c->stream));
   HIPCHK(hipMemsetAsync(b.flag, 0, (size_t)R * 4, c->stream));
   HIPCHK(hipMemsetAsync(c->d_cb, 0, CB_COUNT * 8, c->stream));
+  if (getenv("KC_DEBUG_ADDR"))
+    fprintf(stderr, "kc arenas: rec1 %p (%zu MB) chain1 %p cnt1 %p rec2 %p chain2 %p ovf1 %p ovf2 %p\n", (void *)b.rec1, rec1_bytes >> 20,
+            (void *)b.chain1, (void *)b.cnt1, (void *)b.rec2, (void *)b.chain2, (void *)b.ovf1, (void *)b.ovf2);
   c->bk_bytes = rec1_bytes + rec2_bytes + (b.ovf1_cap + b.ovf2_cap) * w + nseg * (g.L1MAX + 1) * 4 + (size_t)R * (g.L2MAX + 2) * 4;
   c->bk_capacity = bcap;
   c->bk_ready = true;
@@ -1153,6 +1156,80 @@ extern "C" int kc_submit_reads(kc_ctx *c, const uint8_t *bases, const uint8_t *q
 
 extern "C" int kc_submit_packed_reads(kc_ctx *c, const uint8_t *packed, const uint64_t *offsets, uint64_t nreads, int on_device) {
   return submit_reads_impl(c, packed, nullptr, offsets, nreads, on_device, MODE_INSERT, nullptr, 0, FMT_PACKED);
+}
+
+// ---- FASTQ front end (host only) -----------------------------------------------------------------------------------
+extern "C" int kc_fastq_to_packed(const char *text, uint64_t len, int qual_offset, uint8_t *packed, uint64_t packed_capacity,
+                                  uint64_t *offsets, uint64_t reads_capacity, uint64_t *nreads, uint64_t *nbytes) {
+  if ((len && !text) || !nreads || !nbytes) return KC_ERR_INVALID_ARG;
+  // base codes of PackedRead (packed_reads.cpp:99-124): 255 = the reference DIEs
+  uint8_t code[256];
+  memset(code, 255, sizeof(code));
+  const char *acgt = "ACGT";
+  for (int i = 0; i < 4; i++) code[(uint8_t)acgt[i]] = code[(uint8_t)(acgt[i] | 0x20)] = (uint8_t)i;
+  code[(uint8_t)'N'] = code[(uint8_t)'n'] = 4;
+  for (const char *p = "URYKMSWBDHV"; *p; p++) code[(uint8_t)*p] = 4;
+  uint64_t nr = 0, nb = 0, pos = 0, line_no = 0;
+  bool fits = true;
+  auto next_line = [&](uint64_t &b, uint64_t &e) -> bool {  // [b, e): the line without its end and trailing white space
+    if (pos >= len) return false;
+    b = pos;
+    while (pos < len && text[pos] != '\n') pos++;
+    e = pos;
+    if (pos < len) pos++;
+    while (e > b && (text[e - 1] == '\r' || text[e - 1] == ' ' || text[e - 1] == '\t')) e--;
+    line_no++;
+    return true;
+  };
+  if (offsets && reads_capacity + 1 > 0) offsets[0] = 0;
+  for (;;) {
+    uint64_t b0, e0, b1, e1, b2, e2, b3, e3;
+    if (!next_line(b0, e0)) break;
+    if (e0 == b0 && pos >= len) break;  // a final empty line
+    if (!next_line(b1, e1) || !next_line(b2, e2) || !next_line(b3, e3)) {
+      snprintf(g_last_error, sizeof(g_last_error), "FASTQ ends inside the record that starts at line %llu", (unsigned long long)(line_no - (line_no - 1) % 4));
+      return KC_ERR_INVALID_ARG;
+    }
+    if (e0 == b0 || text[b0] != '@') {
+      snprintf(g_last_error, sizeof(g_last_error), "Invalid FASTQ: expected read name (@) at line %llu", (unsigned long long)(line_no - 3));
+      return KC_ERR_INVALID_ARG;
+    }
+    if (e2 == b2 || text[b2] != '+') {
+      snprintf(g_last_error, sizeof(g_last_error), "Invalid FASTQ: expected '+' at line %llu", (unsigned long long)(line_no - 1));
+      return KC_ERR_INVALID_ARG;
+    }
+    const uint64_t sl = e1 - b1;
+    if (sl != e3 - b3) {
+      snprintf(g_last_error, sizeof(g_last_error), "Invalid FASTQ: sequence length %llu != %llu quals length at line %llu",
+               (unsigned long long)sl, (unsigned long long)(e3 - b3), (unsigned long long)(line_no - 2));
+      return KC_ERR_INVALID_ARG;
+    }
+    const bool room = fits && packed && offsets && nr < reads_capacity && nb + sl <= packed_capacity;
+    for (uint64_t i = 0; i < sl; i++) {
+      const uint8_t cb = code[(uint8_t)text[b1 + i]];
+      if (cb == 255) {
+        snprintf(g_last_error, sizeof(g_last_error), "Illegal char in comp nucleotide (int=%d) at line %llu", (int)(uint8_t)text[b1 + i],
+                 (unsigned long long)(line_no - 2));
+        return KC_ERR_BAD_BASE;
+      }
+      if (room) {
+        int q = (int)(uint8_t)text[b3 + i] - qual_offset;
+        if (q > 31) q = 31;
+        packed[nb + i] = (uint8_t)(cb | ((uint8_t)q << 3));  // like the reference's (unsigned char)std::min(q, 31) << 3
+      }
+    }
+    if (!room) fits = false;
+    nb += sl;
+    nr++;
+    if (room) offsets[nr] = nb;
+  }
+  *nreads = nr;
+  *nbytes = nb;
+  if (!fits && (nr || nb)) {
+    snprintf(g_last_error, sizeof(g_last_error), "%llu reads with %llu bases do not fit the arrays", (unsigned long long)nr, (unsigned long long)nb);
+    return KC_ERR_CAPACITY;
+  }
+  return KC_OK;
 }
 
 extern "C" int kc_submit_seq_block(kc_ctx *c, const char *seqs, uint64_t len, int on_device) {

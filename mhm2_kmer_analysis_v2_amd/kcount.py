@@ -264,6 +264,21 @@ def kmer_to_string(words, k):
     return "".join("ACGT"[(int(words[i // 32]) >> (2 * (31 - (i % 32)))) & 3] for i in range(k))
 
 
+def fastq_to_packed(text, qual_offset=33):
+    """FASTQ text (bytes) -> (packed u8, offsets u64): the read cache's bytes of src/packed_reads.cpp:99-126, ready for
+    KmerCounter.submit_packed_reads.  Host only (FastqReader::get_next_fq_record's unpaired pass, src/fastq.cpp:1028+)."""
+    data = text.encode() if isinstance(text, str) else bytes(text)
+    n, nb = C.c_uint64(0), C.c_uint64(0)
+    st = lib().kc_fastq_to_packed(data, len(data), qual_offset, None, 0, None, 0, C.byref(n), C.byref(nb))
+    if st not in (_lib.KC_OK, _lib.KC_ERR_CAPACITY):
+        check(st, "kc_fastq_to_packed")
+    packed = np.zeros(max(nb.value, 1), dtype=np.uint8)
+    offs = np.zeros(n.value + 1, dtype=np.uint64)
+    check(lib().kc_fastq_to_packed(data, len(data), qual_offset, packed.ctypes.data, nb.value, offs.ctypes.data, n.value, C.byref(n),
+                                   C.byref(nb)), "kc_fastq_to_packed")
+    return packed[:nb.value], offs
+
+
 def analyze_kmers(kmer_len, qual_offset, bases, quals, offsets, dmin_thres=2, device=0, max_elems=0, tuning=None):
     """analyze_kmers (src/kcount/kcount.cpp:142-161) for one shard: returns sorted results and stats."""
     with KmerCounter(kmer_len, qual_offset, dmin_thres, device=device, max_elems=max_elems, tuning=tuning) as kc:

@@ -52,7 +52,10 @@ def parse_args():
     ap.add_argument("--no-end-to-end", action="store_true", help="skip the host-resident (PCIe-inclusive) leg at N=1")
     ap.add_argument("--check", action="store_true", help="size-independent result checks after the timed region")
     ap.add_argument("--table-path", action="store_true", help="A/B: force the global-table insert path instead of the bucketed one")
-    ap.add_argument("--force-sharded", action="store_true", help="run the N>1 code path (bin by owner, exchange, insert records) even at N=1")
+    ap.add_argument("--force-sharded", action="store_true", help="run the N>1 code path (extract per block, exchange, receive) even at N=1")
+    ap.add_argument("--shard-flow", choices=["auto", "single-pass", "records"], default="auto",
+                    help="N>1: single-pass = a shard owns level-1 buckets (kc_shard_*), records = hash ownership "
+                         "(kc_extract_partition / kc_insert_records); auto = single-pass when the shard's share of the regions holds its k-mers")
     ap.add_argument("--tune", default="", help="A/B: bucketed-path geometry overrides, e.g. slots=2048,p1=1024,p2=1024")
     return ap.parse_args()
 
@@ -205,8 +208,22 @@ def main():
     genome_kmers = 64 * 4_000_000
     est_unique = int((genome_kmers + world * nreads * L * params.sub_error_rate * k * 1.05) / world) + (1 << 20)
     ap_tuning = dict(mode=1) if a.table_path else ({k: int(v) for k, v in (kv.split("=") for kv in a.tune.split(","))} if a.tune else None)
-    kc = pkg.KmerCounter(k, device=local_rank, rank_me=rank, rank_n=world, max_elems=est_unique, time_kernels=True,
-                         max_kmers_buffered=int(nreads * (L - k - 1) * 1.02) + (1 << 20), tuning=ap_tuning)
+    # N>1: which exchange.  The single-pass flow costs one pass less on either side, but a shard then builds regions only
+    # for the level-1 buckets it owns: kc_shard_capacity says whether those hold its k-mers (the same on every rank)
+    flow = None
+    if sharded_path:
+        flow = "records" if (a.table_path or a.shard_flow == "records") else "single-pass"
+
+    def make_counter(buckets):
+        return pkg.KmerCounter(k, device=local_rank, rank_me=rank, rank_n=world, max_elems=est_unique, time_kernels=True,
+                               max_kmers_buffered=int(nreads * (L - k - 1) * (1.05 if sharded_path else 1.02)) + (1 << 20), tuning=ap_tuning,
+                               shard_buckets=buckets)
+
+    kc = make_counter(flow == "single-pass")
+    if flow == "single-pass" and a.shard_flow == "auto" and kc.shard_capacity() < est_unique:
+        kc.close()
+        flow = "records"
+        kc = make_counter(False)
     # one explicit stream for everything (torch ops, RCCL enqueue order, the library's kernels): torch's default
     # stream is the null handle, which the library would read as "use your own stream"
     stream = torch.cuda.Stream(device=dev)
@@ -226,7 +243,16 @@ def main():
             offs = d_offs[r0:r1 + 1] - d_offs[r0]
             return kc.extract_partition(d_bases[r0 * L:], d_quals[r0 * L:], offs, send, seg_cap, nreads=r1 - r0)
 
-        sharded = ShardedKmerAnalysis(extract, lambda recv, n: kc.insert_records(recv, n), kc.rec_nl, seg, dev, counter=kc)
+        def shard_extract(block, send, seg_words):
+            r0, r1 = block
+            offs = d_offs[r0:r1 + 1] - d_offs[r0]
+            return kc.shard_extract(d_bases[r0 * L:], d_quals[r0 * L:], offs, send, seg_words, nreads=r1 - r0)
+
+        if flow == "single-pass":
+            seg_words = (int(blk * (L - k - 1) / world * 1.1) * kc.rec_nl + 4096) if world > 1 else 1024
+            sharded = ShardedKmerAnalysis.single_pass(kc, shard_extract, seg_words, dev)
+        else:
+            sharded = ShardedKmerAnalysis(extract, lambda recv, n: kc.insert_records(recv, n), kc.rec_nl, seg, dev, counter=kc)
 
     def step():
         kc.reset()
@@ -325,7 +351,7 @@ def main():
             "scaling": "weak", "vs_baseline": None, "dtype": "u64", "data": "synthetic",
             "config": {"workload": "ArcticSynth-shaped synthetic reads, %d reads x %d bp per GPU, k=%d, %s" % (
                 nreads, L, k, "single-GPU hash table" if world == 1 else "%d shards, RCCL exchange" % world),
-                "reads_per_gpu": nreads, "read_len": L, "k": k, "parallelism": "shard%d" % world},
+                "reads_per_gpu": nreads, "read_len": L, "k": k, "parallelism": "shard%d" % world, "shard_flow": flow},
             "roofline": roof,
             "results": {"total_kmers": st["total_kmers"], "num_unique": st["num_unique"], "capacity": st["capacity"],
                         "table_GB": st["table_bytes"] / 1e9},

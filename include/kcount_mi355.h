@@ -72,6 +72,8 @@ typedef struct kc_config {
 #define KC_FLAG_REFERENCE_OWNER 2u /* owner shard = the reference's KmerDHT::get_kmer_target_rank (quick_hash of the minimizer,
                                      src/kcount/kmer_dht.cpp:117-119,192-196) instead of the k-mer hash: for runs mixed with
                                      unmodified MHM2 ranks; slower (k-m+1 m-mer comparisons per k-mer) */
+#define KC_FLAG_SHARD_BUCKETS 4u /* this context will run the single-pass shard flow (kc_shard_*): its regions are sized for 1/rank_n
+                                 * of the level-1 buckets holding all of max_elems (see kc_shard_capacity) */
 #define KC_FLAG_TIME_KERNELS 1u /* bracket every kernel launch with HIP events on its own stream (kc_get_kernel_times) */
 
 /* Scalars the reference logs (src/kcount/kcount.cpp:94-102,158-160;
@@ -201,6 +203,42 @@ int kc_extract_partition_seq_block(kc_ctx *ctx, const char *seqs, uint64_t len, 
 /* Receiver side: HashTableGPUDriver::insert_supermer/insert_supermer_block
  * (gpu_hash_table.cpp:655-695) for records that arrived from other shards. */
 int kc_insert_records(kc_ctx *ctx, const uint64_t *d_records, uint64_t n);
+
+/* ---- the single-pass shard flow: a shard owns level-1 BUCKETS --------------------------------------------
+ * Same role as kc_extract_partition + kc_insert_records -- the aggregated supermer exchange of
+ * ThreeTierAggrStore<Supermer>::update / KmerDHT::flush_updates (src/kcount/kmer_dht.cpp:143-151,247-258) plus the
+ * owner's insert_supermer_block (gpu_hash_table.cpp:655-695) -- without their two extra passes over the records: the
+ * owner of a k-mer is the owner of the level-1 bucket it falls into (each shard a contiguous range of buckets;
+ * kc_shard_owner), so the sender's ordinary level-1 pass has already sorted its records by destination.  What other
+ * shards own is copied once into one wire segment per destination; what this shard owns never moves; a received segment
+ * is read in place by the owner's level 2.  All shards of an exchange must be created with the same kmer_len,
+ * max_kmers_buffered, max_elems, rank_n and tuning (a segment carries a signature; a mismatch is KC_ERR_INVALID_ARG).
+ * A pass uses either this flow or the hash-ownership entry points (kc_submit_*, kc_insert_records), not both
+ * (KC_ERR_STATE); a context on the global-table path (tuning mode 1, or out of buffer) has only the latter.
+ */
+/* Sender: count_kmers' loop body for one block of reads (src/kcount/kcount.cpp:71-90) + add_supermer for all of it.
+ * d_segments: device buffer of rank_n * seg_words u64; segment d (at d * seg_words) receives what shard d owns,
+ * h_words[d] = how many words of it to ship (0 for rank_me and for an empty block).  A block of R reads of length L
+ * needs about R * (L - k - 1) / rank_n * kc_record_longs(k) * 1.1 + 1024 words per segment.  KC_ERR_CAPACITY when a segment is
+ * too small (the block's k-mers then stay buffered in this context; nothing was shipped) or when the context would
+ * hold more than max_kmers_buffered. */
+int kc_shard_extract(kc_ctx *ctx, const uint8_t *bases, const uint8_t *quals, const uint64_t *offsets, uint64_t nreads, int on_device,
+                     uint64_t *d_segments, uint64_t seg_words, uint64_t *h_words);
+/* Receiver: device memory of the context for `nwords` incoming words (the sum over the senders of one block; the caller
+ * receives each sender's segment into its own 2-word-aligned part of it).  It belongs to the context and stays valid
+ * until kc_reset / kc_destroy; earlier reservations never move. */
+int kc_shard_reserve(kc_ctx *ctx, uint64_t nwords, uint64_t **d_dst);
+/* Receiver: a whole segment from one sender has landed at d_segment (inside a kc_shard_reserve area, ordered before
+ * the context's stream).  It becomes part of this shard's buckets where it lies -- no copy. */
+int kc_shard_commit(kc_ctx *ctx, const uint64_t *d_segment, uint64_t nwords);
+/* Distinct k-mers this shard's regions hold in this flow before they start spilling to the global table: the shard
+ * builds regions only for the buckets it owns, 1/rank_n of the geometry's (at most 2^20 regions of at most 4096 LDS slots
+ * for all shards together).  A caller whose shards expect more than this each should stay with kc_extract_partition +
+ * kc_insert_records, where every shard uses the whole geometry. */
+int kc_shard_capacity(kc_ctx *ctx, uint64_t *max_distinct);
+/* The shard that owns a canonical k-mer in this flow (role of KmerDHT::get_kmer_target_rank, kmer_dht.cpp:192-196).
+ * Depends on the context's geometry: ask a context of the exchange, not kc_owner. */
+int kc_shard_owner(kc_ctx *ctx, const uint64_t *kmer_words, int *owner);
 
 /* ---- the reference's wire format (runs mixed with unmodified MHM2 ranks) -------------------------------- */
 /* kcount_gpu::SupermerInfo (src/kcount/kcount-gpu/parse_and_pack.hpp:50-54), same layout */

@@ -10,6 +10,7 @@ KC_ERR_CAPACITY = -6
 KC_ERR_BAD_BASE = -7
 KC_FLAG_TIME_KERNELS = 1
 KC_FLAG_REFERENCE_OWNER = 2
+KC_FLAG_SHARD_BUCKETS = 4
 
 
 class KcError(RuntimeError):
@@ -77,6 +78,11 @@ SYMBOLS = {
                                        C.c_uint64, C.c_void_p]),
     "kc_extract_partition_seq_block": (C.c_int, [C.c_void_p, C.c_void_p, C.c_uint64, C.c_int, C.c_void_p, C.c_uint64, C.c_void_p]),
     "kc_insert_records": (C.c_int, [C.c_void_p, C.c_void_p, C.c_uint64]),
+    "kc_shard_extract": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_uint64, C.c_int, C.c_void_p, C.c_uint64, C.c_void_p]),
+    "kc_shard_reserve": (C.c_int, [C.c_void_p, C.c_uint64, C.POINTER(C.c_void_p)]),
+    "kc_shard_commit": (C.c_int, [C.c_void_p, C.c_void_p, C.c_uint64]),
+    "kc_shard_owner": (C.c_int, [C.c_void_p, C.c_void_p, C.POINTER(C.c_int)]),
+    "kc_shard_capacity": (C.c_int, [C.c_void_p, C.POINTER(C.c_uint64)]),
     "kc_build_supermers": (C.c_int, [C.c_void_p, C.c_void_p, C.c_uint64, C.c_int, C.c_void_p, C.c_uint32, C.POINTER(C.c_uint32),
                                       C.POINTER(C.c_uint32), C.c_void_p]),
     "kc_submit_packed_supermers": (C.c_int, [C.c_void_p, C.c_void_p, C.c_uint64, C.c_int]),

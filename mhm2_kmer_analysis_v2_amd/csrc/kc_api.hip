@@ -19,6 +19,7 @@
 
 #include "../../include/kcount_mi355.h"
 #include "kc_bucketed.hpp"
+#include "kc_shard.hpp"
 #include "kc_supermer.hpp"
 
 using namespace kc;
@@ -37,11 +38,11 @@ static int hip_fail(hipError_t e, const char *what, int line) {
   } while (0)
 
 enum { KT_EXTRACT_INSERT = 0, KT_EXTRACT_BIN, KT_INSERT_RECORDS, KT_FINALIZE, KT_TILE_FIRST, KT_REHASH, KT_L1_READS, KT_L1_RECORDS,
-       KT_L2_SPLIT, KT_COUNT_REGIONS, KT_FALLBACK, KT_COUNT };
+       KT_L2_SPLIT, KT_COUNT_REGIONS, KT_FALLBACK, KT_SHARD_PACK, KT_COUNT };
 static const char *const kt_names[KT_COUNT] = {"kc_extract_kernel<insert>", "kc_bin_reads_kernel", "kc_insert_records_kernel",
                                                "kc_finalize_kernel", "kc_tile_first_kernel", "kc_rehash_kernel",
                                                "kc_l1_reads_kernel", "kc_l1_records_kernel", "kc_l2_split_kernel",
-                                               "kc_count_kernel", "kc_flagged_to_table_kernel"};
+                                               "kc_count_kernel", "kc_flagged_to_table_kernel", "kc_shard_pack_kernel"};
 struct kt_pending {
   hipEvent_t start, stop;
   int kind;
@@ -114,11 +115,29 @@ struct kc_ctx {
   uint32_t bk_rot;       // first writer of the next level-1 launch
   size_t bk_bytes;
   int num_cus;
+  // shard flow (kc_shard.hpp): ownership by level-1 bucket
+  struct ShardExtent {
+    uint64_t *p;
+    uint64_t cap, used;  // words
+  };
+  struct {
+    bool flow;         // this pass runs the shard flow (kc_shard_extract / kc_shard_commit were used)
+    bool extracting;   // inside kc_shard_extract: level 1 keeps every k-mer, whoever owns it
+    uint64_t *d_plan;  // off[PMAX], totals[SHARD_MAX], flags[SHARD_MAX], loose[SHARD_MAX]
+    uint64_t *h_plan;  // pinned mirror of totals, flags, loose (+ SHARD_MAX header words)
+    uint32_t F;        // flat sources (received segments) of this pass
+    uint32_t nbo;      // buckets this shard owns (row length of d_cnt / d_at)
+    uint32_t *d_cnt;   // [FLAT_MAX][nbo]
+    uint64_t *d_at;    // [FLAT_MAX][nbo]
+    uint64_t sent, received;  // records, this pass
+  } sh;
+  std::vector<ShardExtent> sh_extents;  // where received segments live until the regions are built (kc_shard_reserve)
 };
 
 // ---- kernel timing (HIP events on the launch stream) --------------------------------------------
 static void bk_free(kc_ctx *c);
 static void host_pipe_free(kc_ctx *c);
+static void shard_free(kc_ctx *c);
 
 struct KernelTimer {
   kc_ctx *c;
@@ -411,6 +430,7 @@ extern "C" void kc_destroy(kc_ctx *c) {
   if (c->d_sm_ctr) (void)hipFree(c->d_sm_ctr);
   host_pipe_free(c);
   bk_free(c);
+  shard_free(c);
   if (c->d_cb) (void)hipFree(c->d_cb);
   if (c->h_cb) (void)hipHostFree(c->h_cb);
   if (c->own_stream) (void)hipStreamDestroy(c->own_stream);
@@ -422,6 +442,31 @@ extern "C" int kc_set_stream(kc_ctx *c, void *s) {
   HIPCHK(hipStreamSynchronize(c->stream));
   c->stream = s ? (hipStream_t)s : c->own_stream;
   return KC_OK;
+}
+
+// a new pass: no flat sources, the extents empty (kept, unless the geometry may change)
+static void shard_reset(kc_ctx *c, bool geometry_changes) {
+  c->sh.flow = c->sh.extracting = false;
+  c->sh.F = 0;
+  c->sh.sent = c->sh.received = 0;
+  for (auto &e : c->sh_extents) e.used = 0;
+  if (geometry_changes) {
+    if (c->sh.d_cnt) (void)hipFree(c->sh.d_cnt);
+    if (c->sh.d_at) (void)hipFree(c->sh.d_at);
+    c->sh.d_cnt = nullptr;
+    c->sh.d_at = nullptr;
+    c->sh.nbo = 0;
+  }
+}
+
+static void shard_free(kc_ctx *c) {
+  shard_reset(c, true);
+  for (auto &e : c->sh_extents)
+    if (e.p) (void)hipFree(e.p);
+  c->sh_extents.clear();
+  if (c->sh.d_plan) (void)hipFree(c->sh.d_plan);
+  if (c->sh.h_plan) (void)hipHostFree(c->sh.h_plan);
+  c->sh.d_plan = c->sh.h_plan = nullptr;
 }
 
 extern "C" int kc_reset(kc_ctx *c, int new_k) {
@@ -466,6 +511,7 @@ extern "C" int kc_reset(kc_ctx *c, int new_k) {
   }
   HIPCHK(hipMemsetAsync(c->d_cb, 0, CB_COUNT * 8, c->stream));
   c->bk_level2 = c->bk_flagged = c->table_mode = c->started = false;
+  shard_reset(c, c->nl != old_nl || (c->nl == 1 && new_k != old_k));
   HIPCHK(hipStreamSynchronize(c->stream));
   return KC_OK;
 }
@@ -503,7 +549,11 @@ static int bk_init(kc_ctx *c) {
   Geom &g = c->gm;
   memset(&g, 0, sizeof(g));
   const uint64_t bcap = c->cfg.max_kmers_buffered ? c->cfg.max_kmers_buffered : (1ULL << 26);
-  const double est = c->cfg.max_elems ? (double)c->cfg.max_elems : 0.35 * (double)bcap;  // 1/depth(4) + error share, kmer_dht.cpp:126-131
+  double est = c->cfg.max_elems ? (double)c->cfg.max_elems : 0.35 * (double)bcap;  // 1/depth(4) + error share, kmer_dht.cpp:126-131
+  // single-pass shard flow: this shard's k-mers all fall into the 1/rank_n of the buckets it owns, so the geometry as a
+  // whole is sized as if it held rank_n times as many
+  const double flow_n = ((c->cfg.flags & KC_FLAG_SHARD_BUCKETS) && c->cfg.rank_n > 1) ? (double)c->cfg.rank_n : 1.0;
+  est *= flow_n;
   const uint32_t smax = count_smax(c->nl);
   // Region tables are meant to run at about 0.4 load: the lanes of a wave probe in lock step, so a wave pays for its
   // longest probe, and the count kernel's time grows steeply with the load (measured: 1.6x from 0.4 to 0.6), more
@@ -551,7 +601,7 @@ static int bk_init(kc_ctx *c) {
   if (g.G < 1) g.G = 1;
   const uint64_t R = (uint64_t)g.P1 * g.P2;
   // chunk sizes: at most ~1/8 of a destination's mean share, within [16, 512] / [16, 1024] records
-  const double mean1 = (double)bcap / ((double)g.G * g.P1), mean2 = (double)bcap / (double)R;
+  const double mean1 = (double)bcap / ((double)g.G * g.P1), mean2 = flow_n * (double)bcap / (double)R;
   g.log2CH1 = t.chunk1 ? ilog2(t.chunk1) : std::min<uint32_t>(9, std::max<uint32_t>(4, ilog2((uint64_t)(mean1 / 8) + 1)));
   g.log2CH2 = t.chunk2 ? ilog2(t.chunk2) : std::min<uint32_t>(10, std::max<uint32_t>(4, ilog2((uint64_t)(mean2 / 8) + 1)));
   const uint64_t CH1 = 1ULL << g.log2CH1, CH2 = 1ULL << g.log2CH2;
@@ -624,7 +674,9 @@ static int bk_ovf1_room(kc_ctx *c, uint64_t want, uint64_t *room) {
     return KC_ERR_CAPACITY;
   }
   uint64_t used = std::min<uint64_t>(c->h_cb[CB_OVF1], c->bb.ovf1_cap);
-  if (used && c->bb.ovf1_cap - used < want) {
+  // (inside a kc_shard_extract the list also holds records of other shards, which must not reach this shard's table: the
+  // launch is bounded by the room that is left, and the list is emptied when the block is packed)
+  if (used && c->bb.ovf1_cap - used < want && !c->sh.extracting) {
     rc = ensure_room(c, used);
     if (rc) return rc;
     {
@@ -664,7 +716,7 @@ template <int NL> static bool use_cp(const kc_ctx *c) { return NL == 1 && c->gm.
 
 template <int NL, int FMT>
 static int launch_l1_reads_t(kc_ctx *c, const ExtractArgs &a, uint64_t nsuper) {
-  const bool sh = c->cfg.rank_n > 1;
+  const bool sh = c->cfg.rank_n > 1 && !c->sh.extracting;  // the shard flow ships whole buckets instead of testing k-mers
   // compact records at k = 21 (MHM2's first and only one-word k of its default sweep, src/options.hpp:80): the
   // instantiation made for that k; any other k takes the general one
   constexpr int K21 = NL == 1 ? 21 : 0;
@@ -816,6 +868,9 @@ static int bk_drain_to_table(kc_ctx *c) {
 }
 
 static bool bk_active(const kc_ctx *c) { return c->tuning.mode != 1 && !c->table_mode; }
+// A shard of several that has started the shard flow owns level-1 buckets, not hash values: the entry points that test
+// ownership per k-mer (kc_submit_*, kc_insert_records) would put records where its level 2 never looks.
+static bool shard_flow_only(const kc_ctx *c) { return c->sh.flow && c->cfg.rank_n > 1; }
 
 // ---- extraction launches -----------------------------------------------------------------------
 template <int NL, int FMT>
@@ -894,6 +949,11 @@ static int run_extract_device(kc_ctx *c, const uint8_t *bases, const uint8_t *qu
       chunk_tiles = std::min<uint64_t>(chunk_tiles, (1ULL << 28) / span);
     }
     uint64_t nt = std::min<uint64_t>(chunk_tiles, ((uint64_t)(end - p0) + span - 1) / span);
+    if (bk && over_capacity && c->sh.flow) {
+      snprintf(g_last_error, sizeof(g_last_error), "shard flow: more k-mers than max_kmers_buffered (%llu): raise it, or use kc_extract_partition / kc_insert_records",
+               (unsigned long long)c->bk_capacity);
+      return KC_ERR_CAPACITY;
+    }
     if (bk && over_capacity) {
       int rc = bk_drain_to_table(c);  // out of buffer room: this and every later chunk take the table path
       if (rc) return rc;
@@ -1130,6 +1190,7 @@ static int submit_reads_impl(kc_ctx *c, const uint8_t *bases, const uint8_t *qua
                              int on_device, int mode, uint64_t *d_records, uint64_t seg_capacity, int fmt = FMT_READS) {
   if (!c || (nreads && (!bases || (fmt == FMT_READS && !quals) || !offsets))) return KC_ERR_INVALID_ARG;
   if ((c->finalized || c->bk_level2) && mode == MODE_INSERT) return KC_ERR_STATE;  // extraction alone never touches the table
+  if (mode == MODE_INSERT && shard_flow_only(c) && !c->sh.extracting) return KC_ERR_STATE;
   HIPCHK(hipSetDevice(c->cfg.device));
   if (!nreads) return KC_OK;
   if (on_device) {
@@ -1234,7 +1295,7 @@ extern "C" int kc_fastq_to_packed(const char *text, uint64_t len, int qual_offse
 
 extern "C" int kc_submit_seq_block(kc_ctx *c, const char *seqs, uint64_t len, int on_device) {
   if (!c || (len && !seqs)) return KC_ERR_INVALID_ARG;
-  if (c->finalized || c->bk_level2) return KC_ERR_STATE;
+  if (c->finalized || c->bk_level2 || shard_flow_only(c)) return KC_ERR_STATE;
   HIPCHK(hipSetDevice(c->cfg.device));
   if (!len) return KC_OK;
   const uint8_t *d = (const uint8_t *)seqs;
@@ -1422,7 +1483,7 @@ static int table_insert_records(kc_ctx *c, const uint64_t *d_records, uint64_t n
 
 extern "C" int kc_insert_records(kc_ctx *c, const uint64_t *d_records, uint64_t n) {
   if (!c || (n && !d_records)) return KC_ERR_INVALID_ARG;
-  if (c->finalized || c->bk_level2) return KC_ERR_STATE;
+  if (c->finalized || c->bk_level2 || shard_flow_only(c)) return KC_ERR_STATE;
   HIPCHK(hipSetDevice(c->cfg.device));
   if (!n) return KC_OK;
   c->started = true;
@@ -1461,6 +1522,269 @@ extern "C" int kc_insert_records(kc_ctx *c, const uint64_t *d_records, uint64_t 
     }
   }
   return table_insert_records(c, d_records, n, 1u);
+}
+
+// ---- shard flow: ownership by level-1 bucket (kernels and the wire format in kc_shard.hpp) -------------------
+static uint64_t shard_signature(const kc_ctx *c) {
+  return (0x4B53ULL << 48) | ((uint64_t)c->gm.P1 << 32) | ((uint64_t)c->k << 16) | ((uint64_t)c->nl << 12) | ((uint64_t)(c->gm.cp ? 1 : 0) << 8) |
+         (uint64_t)c->cfg.rank_n;
+}
+
+static int shard_init(kc_ctx *c) {
+  if (c->sh.d_plan) return KC_OK;
+  HIPCHK(hipMalloc((void **)&c->sh.d_plan, ((size_t)PMAX + 3 * SHARD_MAX) * 8));
+  HIPCHK(hipHostMalloc((void **)&c->sh.h_plan, (size_t)4 * SHARD_MAX * 8, hipHostMallocDefault));
+  return KC_OK;
+}
+
+template <int NL>
+static void launch_shard_pack(kc_ctx *c, uint64_t *segs, uint64_t seg_words, const uint64_t *off, const uint64_t *flags) {
+  const uint32_t Q = 4;  // workgroups per bucket
+  KernelTimer kt(c, KT_SHARD_PACK);
+  hipLaunchKernelGGL(kc_shard_pack_kernel<NL>, dim3(c->gm.P1 * Q), dim3(WGB), 0, c->stream, c->gm, c->bb, (uint32_t)c->cfg.rank_me,
+                     (uint32_t)c->cfg.rank_n, segs, seg_words, off, flags, Q);
+}
+
+template <int NL>
+static void launch_shard_route(kc_ctx *c, uint64_t n1, uint64_t *segs, uint64_t seg_words, const uint64_t *totals, uint64_t *loose, uint64_t *flags) {
+  auto kern = use_cp<NL>(c) ? kc_shard_route_ovf1_kernel<NL, NL == 1> : kc_shard_route_ovf1_kernel<NL, false>;
+  KernelTimer kt(c, KT_FALLBACK);
+  hipLaunchKernelGGL(kern, dim3((unsigned)std::min<uint64_t>((n1 + TPB - 1) / TPB, 256 * 32)), dim3(TPB), 0, c->stream, c->gm, c->bb, n1,
+                     (uint32_t)c->cfg.rank_me, (uint32_t)c->cfg.rank_n, segs, seg_words, totals, loose, flags, c->table, c->d_ctrs);
+}
+
+template <int NL>
+static void launch_shard_loose(kc_ctx *c, const uint64_t *recs, uint64_t n) {
+  auto kern = use_cp<NL>(c) ? kc_shard_loose_kernel<NL, NL == 1> : kc_shard_loose_kernel<NL, false>;
+  KernelTimer kt(c, KT_FALLBACK);
+  hipLaunchKernelGGL(kern, dim3((unsigned)std::min<uint64_t>((n + TPB - 1) / TPB, 256 * 32)), dim3(TPB), 0, c->stream, c->gm, c->bb, recs, n,
+                     c->table, c->d_ctrs);
+}
+
+extern "C" int kc_shard_extract(kc_ctx *c, const uint8_t *bases, const uint8_t *quals, const uint64_t *offsets, uint64_t nreads, int on_device,
+                                uint64_t *d_segments, uint64_t seg_words, uint64_t *h_words) {
+  if (!c || !h_words) return KC_ERR_INVALID_ARG;
+  const uint32_t n = (uint32_t)c->cfg.rank_n, me = (uint32_t)c->cfg.rank_me;
+  if (n > 1 && (!d_segments || seg_words < SHARD_HDR + PMAX / 2)) return KC_ERR_INVALID_ARG;
+  for (uint32_t d = 0; d < n; d++) h_words[d] = 0;
+  if (c->finalized || c->bk_level2) return KC_ERR_STATE;
+  if (!bk_active(c)) {
+    snprintf(g_last_error, sizeof(g_last_error), "the shard flow needs the bucketed path (this context is on the global table): use kc_extract_partition / kc_insert_records");
+    return KC_ERR_STATE;
+  }
+  if (n > 1 && c->started && !c->sh.flow) {
+    snprintf(g_last_error, sizeof(g_last_error), "this pass already took k-mers by hash ownership (kc_submit_* / kc_insert_records): kc_reset first");
+    return KC_ERR_STATE;
+  }
+  HIPCHK(hipSetDevice(c->cfg.device));
+  int rc = bk_init(c);
+  if (rc) return rc;
+  if (n > c->gm.P1) {
+    snprintf(g_last_error, sizeof(g_last_error), "more shards (%u) than level-1 buckets (%u)", n, c->gm.P1);
+    return KC_ERR_INVALID_ARG;
+  }
+  c->sh.flow = true;
+  c->sh.extracting = true;
+  rc = submit_reads_impl(c, bases, quals, offsets, nreads, on_device, MODE_INSERT, nullptr, 0);
+  c->sh.extracting = false;
+  if (rc) return rc;
+  if (n == 1 || !nreads) return KC_OK;  // a single shard owns every bucket: nothing leaves
+  rc = shard_init(c);
+  if (rc) return rc;
+  uint64_t *off = c->sh.d_plan, *totals = off + PMAX, *flags = totals + SHARD_MAX, *loose = flags + SHARD_MAX;
+  HIPCHK(hipMemsetAsync(loose, 0, SHARD_MAX * 8, c->stream));
+  hipLaunchKernelGGL(kc_shard_plan_kernel, dim3(1), dim3(WGB), 0, c->stream, c->gm, c->bb, me, n, d_segments, seg_words, shard_signature(c),
+                     (uint32_t)c->nl, off, totals, flags);
+  switch (c->nl) {
+    case 1: launch_shard_pack<1>(c, d_segments, seg_words, off, flags); break;
+    case 2: launch_shard_pack<2>(c, d_segments, seg_words, off, flags); break;
+    case 3: launch_shard_pack<3>(c, d_segments, seg_words, off, flags); break;
+    default: launch_shard_pack<4>(c, d_segments, seg_words, off, flags); break;
+  }
+  c->num_gpu_calls += 2;
+  HIPCHK(hipGetLastError());
+  // what found no room at level 1: this shard's own to its table, the rest behind the buckets of its destination
+  rc = sync_cb(c);
+  if (rc) return rc;
+  if (c->h_cb[CB_FATAL]) {
+    snprintf(g_last_error, sizeof(g_last_error), "k-mer buffer: records were lost (fatal bits %llu)", (unsigned long long)c->h_cb[CB_FATAL]);
+    return KC_ERR_CAPACITY;
+  }
+  const uint64_t n1 = std::min<uint64_t>(c->h_cb[CB_OVF1], c->bb.ovf1_cap);
+  if (n1) {
+    rc = ensure_room(c, n1);
+    if (rc) return rc;
+    switch (c->nl) {
+      case 1: launch_shard_route<1>(c, n1, d_segments, seg_words, totals, loose, flags); break;
+      case 2: launch_shard_route<2>(c, n1, d_segments, seg_words, totals, loose, flags); break;
+      case 3: launch_shard_route<3>(c, n1, d_segments, seg_words, totals, loose, flags); break;
+      default: launch_shard_route<4>(c, n1, d_segments, seg_words, totals, loose, flags); break;
+    }
+    HIPCHK(hipGetLastError());
+    HIPCHK(hipMemsetAsync(c->d_cb + CB_OVF1, 0, 8, c->stream));
+  }
+  {
+    const size_t cells = (size_t)c->gm.G * c->gm.P1;
+    hipLaunchKernelGGL(kc_shard_release_kernel, dim3((unsigned)((cells + 255) / 256)), dim3(256), 0, c->stream, c->gm, c->bb, me, n, totals, flags,
+                       c->d_ctrs);
+    c->num_gpu_calls++;
+  }
+  HIPCHK(hipGetLastError());
+  HIPCHK(hipMemcpyAsync(c->sh.h_plan, totals, (size_t)3 * SHARD_MAX * 8, hipMemcpyDeviceToHost, c->stream));
+  HIPCHK(hipStreamSynchronize(c->stream));
+  const uint64_t *h_totals = c->sh.h_plan, *h_flags = h_totals + SHARD_MAX, *h_loose = h_flags + SHARD_MAX;
+  uint64_t *h_hdr = c->sh.h_plan + 3 * SHARD_MAX;
+  for (uint32_t d = 0; d < n; d++) {
+    if (d == me) continue;
+    if (h_flags[d]) {
+      snprintf(g_last_error, sizeof(g_last_error), "the segment of shard %u is too small: %llu records (+ %llu loose) do not fit %llu words", d,
+               (unsigned long long)h_totals[d], (unsigned long long)h_loose[d], (unsigned long long)seg_words);
+      return KC_ERR_CAPACITY;
+    }
+    const uint32_t nb = shard_first_bucket(d + 1, c->gm.P1, n) - shard_first_bucket(d, c->gm.P1, n);
+    h_words[d] = shard_header_words(nb) + (h_totals[d] + h_loose[d]) * (uint64_t)c->nl;
+    if (h_loose[d]) {
+      h_hdr[d] = (uint64_t)nb | (h_loose[d] << 32);
+      HIPCHK(hipMemcpyAsync(d_segments + (size_t)d * seg_words + 1, &h_hdr[d], 8, hipMemcpyHostToDevice, c->stream));
+    }
+    c->sh.sent += h_totals[d] + h_loose[d];
+  }
+  return KC_OK;
+}
+
+extern "C" int kc_shard_reserve(kc_ctx *c, uint64_t nwords, uint64_t **d_dst) {
+  if (!c || !d_dst) return KC_ERR_INVALID_ARG;
+  *d_dst = nullptr;
+  if (!nwords) return KC_OK;
+  HIPCHK(hipSetDevice(c->cfg.device));
+  const uint64_t need = (nwords + 1) & ~1ULL;  // 16-byte granules
+  for (auto &e : c->sh_extents) {
+    if (e.cap - e.used >= need) {
+      *d_dst = e.p + e.used;
+      e.used += need;
+      return KC_OK;
+    }
+  }
+  // a new extent (the old ones stay where they are: segments already there are being read): an eighth of the buffer or
+  // what this call needs
+  const uint64_t bcap = c->cfg.max_kmers_buffered ? c->cfg.max_kmers_buffered : (1ULL << 26);
+  kc_ctx::ShardExtent e;
+  e.cap = std::max<uint64_t>(need, std::max<uint64_t>(bcap * (uint64_t)c->nl / 8, 1ULL << 17));
+  e.used = need;
+  e.p = nullptr;
+  HIPCHK(hipMalloc((void **)&e.p, (size_t)e.cap * 8));
+  c->sh_extents.push_back(e);
+  *d_dst = e.p;
+  return KC_OK;
+}
+
+extern "C" int kc_shard_commit(kc_ctx *c, const uint64_t *d_segment, uint64_t nwords) {
+  if (!c || (nwords && !d_segment)) return KC_ERR_INVALID_ARG;
+  if (!nwords) return KC_OK;
+  if (c->finalized || c->bk_level2) return KC_ERR_STATE;
+  const uint32_t n = (uint32_t)c->cfg.rank_n, me = (uint32_t)c->cfg.rank_me;
+  if (n < 2 || !bk_active(c)) return KC_ERR_STATE;
+  if (c->started && !c->sh.flow) return KC_ERR_STATE;
+  bool inside = false;
+  for (auto &e : c->sh_extents) inside |= d_segment >= e.p && d_segment + nwords <= e.p + e.used;
+  if (!inside) {
+    snprintf(g_last_error, sizeof(g_last_error), "kc_shard_commit: the segment does not lie in memory handed out by kc_shard_reserve");
+    return KC_ERR_INVALID_ARG;
+  }
+  HIPCHK(hipSetDevice(c->cfg.device));
+  int rc = bk_init(c);
+  if (rc) return rc;
+  rc = shard_init(c);
+  if (rc) return rc;
+  if (nwords < SHARD_HDR) return KC_ERR_INVALID_ARG;
+  uint64_t *hdr = c->sh.h_plan;
+  HIPCHK(hipMemcpyAsync(hdr, d_segment, SHARD_HDR * 8, hipMemcpyDeviceToHost, c->stream));
+  HIPCHK(hipMemcpyAsync(c->h_ctrs, c->d_ctrs, CTR_COUNT * 8, hipMemcpyDeviceToHost, c->stream));
+  HIPCHK(hipStreamSynchronize(c->stream));
+  const uint32_t lo = shard_first_bucket(me, c->gm.P1, n), nbo = shard_first_bucket(me + 1, c->gm.P1, n) - lo;
+  const uint32_t nb = (uint32_t)hdr[1];
+  const uint64_t loose = hdr[1] >> 32, nrec = hdr[2];
+  if (hdr[0] != shard_signature(c) || nb != nbo || shard_header_words(nb) + (nrec + loose) * (uint64_t)c->nl != nwords) {
+    snprintf(g_last_error, sizeof(g_last_error), "kc_shard_commit: not a segment for this shard (made by a context with another k, geometry or shard count?)");
+    return KC_ERR_INVALID_ARG;
+  }
+  if (c->sh.F >= std::min<uint32_t>(FLAT_MAX, GMAX - c->gm.G)) {
+    snprintf(g_last_error, sizeof(g_last_error), "shard flow: %u segments received in one pass is the limit: use larger blocks", c->sh.F);
+    return KC_ERR_CAPACITY;
+  }
+  if (c->h_ctrs[CTR_INSERTED] + nrec + loose > c->bk_capacity) {
+    snprintf(g_last_error, sizeof(g_last_error), "shard flow: this shard would hold more k-mers than max_kmers_buffered (%llu)", (unsigned long long)c->bk_capacity);
+    return KC_ERR_CAPACITY;
+  }
+  if (c->sh.nbo != nbo || !c->sh.d_cnt) {  // first segment for this geometry
+    if (c->sh.d_cnt) (void)hipFree(c->sh.d_cnt);
+    if (c->sh.d_at) (void)hipFree(c->sh.d_at);
+    c->sh.d_cnt = nullptr;
+    c->sh.d_at = nullptr;
+    HIPCHK(hipMalloc((void **)&c->sh.d_cnt, (size_t)FLAT_MAX * nbo * 4));
+    HIPCHK(hipMalloc((void **)&c->sh.d_at, (size_t)FLAT_MAX * nbo * 8));
+    c->sh.nbo = nbo;
+  }
+  c->sh.flow = true;
+  c->started = true;
+  const uint32_t f = c->sh.F++;
+  hipLaunchKernelGGL(kc_shard_index_kernel, dim3(1), dim3(WGB), 0, c->stream, d_segment, nb, (uint32_t)c->nl, c->sh.d_cnt + (size_t)f * nbo,
+                     c->sh.d_at + (size_t)f * nbo, c->d_ctrs);
+  c->num_gpu_calls++;
+  HIPCHK(hipGetLastError());
+  if (loose) {
+    rc = ensure_room(c, loose);
+    if (rc) return rc;
+    const uint64_t *lp = d_segment + shard_header_words(nb) + nrec * (uint64_t)c->nl;
+    switch (c->nl) {
+      case 1: launch_shard_loose<1>(c, lp, loose); break;
+      case 2: launch_shard_loose<2>(c, lp, loose); break;
+      case 3: launch_shard_loose<3>(c, lp, loose); break;
+      default: launch_shard_loose<4>(c, lp, loose); break;
+    }
+    HIPCHK(hipGetLastError());
+  }
+  c->sh.received += nrec + loose;
+  return KC_OK;
+}
+
+extern "C" int kc_shard_capacity(kc_ctx *c, uint64_t *max_distinct) {
+  if (!c || !max_distinct) return KC_ERR_INVALID_ARG;
+  *max_distinct = 0;
+  if (!bk_active(c)) return KC_ERR_STATE;
+  HIPCHK(hipSetDevice(c->cfg.device));
+  int rc = bk_init(c);
+  if (rc) return rc;
+  const uint32_t n = (uint32_t)c->cfg.rank_n, me = (uint32_t)c->cfg.rank_me;
+  const uint64_t mine = shard_first_bucket(me + 1, c->gm.P1, n) - shard_first_bucket(me, c->gm.P1, n);
+  *max_distinct = (uint64_t)(0.55 * (double)(mine * c->gm.P2) * (double)c->gm.S);  // the load bk_init accepts
+  return KC_OK;
+}
+
+extern "C" int kc_shard_owner(kc_ctx *c, const uint64_t *kmer, int *owner) {
+  if (!c || !kmer || !owner) return KC_ERR_INVALID_ARG;
+  if (!bk_active(c)) return KC_ERR_STATE;
+  HIPCHK(hipSetDevice(c->cfg.device));
+  int rc = bk_init(c);  // the geometry decides
+  if (rc) return rc;
+  uint64_t a[KC_MAX_LONGS] = {0, 0, 0, 0};
+  for (int j = 0; j < c->nl_ext; j++) a[j] = kmer[j];
+  uint32_t b1;
+  if (c->gm.cp) {
+    const uint64_t mix = kc_feistel_fwd(a[0] >> (64u - c->gm.k2), c->k);
+    b1 = (uint32_t)(mix >> (c->gm.k2 - c->gm.la));
+  } else {
+    uint64_t h;
+    switch (c->nl) {
+      case 1: { uint64_t x[1] = {a[0]}; h = kc_hash<1>(x); break; }
+      case 2: { uint64_t x[2] = {a[0], a[1]}; h = kc_hash<2>(x); break; }
+      case 3: { uint64_t x[3] = {a[0], a[1], a[2]}; h = kc_hash<3>(x); break; }
+      default: h = kc_hash<4>(a); break;
+    }
+    b1 = (uint32_t)((((uint32_t)h & 0xFFFFu) * c->gm.P1) >> 16);
+  }
+  *owner = (int)shard_of_bucket(b1, c->gm.P1, (uint32_t)c->cfg.rank_n);
+  return KC_OK;
 }
 
 extern "C" int kc_flush(kc_ctx *c) {
@@ -1546,15 +1870,29 @@ template <int NL>
 static int bk_level2_t(kc_ctx *c) {
   // short register form: compact records whose mix fits 32 bits below the level-1 bucket
   const bool cr = use_cp<NL>(c) && c->gm.k2 - c->gm.la <= 32;
-  auto kern = use_cp<NL>(c) ? (cr ? kc_l2_split_kernel<NL, NL == 1, NL == 1> : kc_l2_split_kernel<NL, NL == 1, false>)
-                            : kc_l2_split_kernel<NL, false, false>;
+  const bool fl = shard_flow_only(c);  // only this shard's buckets, their flat sources behind their chains
+  auto kern = use_cp<NL>(c) ? (cr ? (fl ? kc_l2_split_kernel<NL, NL == 1, NL == 1, true> : kc_l2_split_kernel<NL, NL == 1, NL == 1, false>)
+                                  : (fl ? kc_l2_split_kernel<NL, NL == 1, false, true> : kc_l2_split_kernel<NL, NL == 1, false, false>))
+                            : (fl ? kc_l2_split_kernel<NL, false, false, true> : kc_l2_split_kernel<NL, false, false, false>);
   int rc = set_dyn_lds(kern, lds_l2<NL>());
   if (rc) return rc;
-  hipLaunchKernelGGL(kc_bucket_prefix_kernel, dim3(1), dim3(WGB), 0, c->stream, c->gm, c->bb, c->d_cb);
+  FlatSrc fs;
+  memset(&fs, 0, sizeof(fs));
+  fs.b_hi = c->gm.P1;
+  if (fl) {
+    fs.cnt = c->sh.d_cnt;
+    fs.at = c->sh.d_at;
+    fs.F = c->sh.F;
+    fs.b_lo = shard_first_bucket((uint32_t)c->cfg.rank_me, c->gm.P1, (uint32_t)c->cfg.rank_n);
+    fs.b_hi = shard_first_bucket((uint32_t)c->cfg.rank_me + 1, c->gm.P1, (uint32_t)c->cfg.rank_n);
+    fs.nbo = fs.b_hi - fs.b_lo;
+  }
+  hipLaunchKernelGGL(kc_bucket_prefix_kernel, dim3(1), dim3(WGB), 0, c->stream, c->gm, c->bb, fs, c->d_cb);
   c->num_gpu_calls++;
-  {
+  if (fs.b_hi > fs.b_lo) {
     KernelTimer kt(c, KT_L2_SPLIT);
-    hipLaunchKernelGGL(kern, dim3(std::min<unsigned>(c->gm.P1, (unsigned)c->num_cus)), dim3(WGB), lds_l2<NL>(), c->stream, c->gm, c->bb, c->d_cb);
+    hipLaunchKernelGGL(kern, dim3(std::min<unsigned>(fs.b_hi - fs.b_lo, (unsigned)c->num_cus)), dim3(WGB), lds_l2<NL>(), c->stream, c->gm, c->bb,
+                       fs, c->d_cb);
   }
   HIPCHK(hipGetLastError());
   rc = sync_cb(c);

@@ -84,6 +84,16 @@ struct BucketBufs {
   uint64_t ovf1_cap, ovf2_cap;
 };
 
+// The shard flow (kc_shard.hpp): besides its own G chains a bucket may have flat sources -- dense runs of records
+// received from other shards, one per received segment -- and a shard builds regions only for the buckets it owns.
+constexpr uint32_t FLAT_MAX = 256;  // flat sources level 2 can walk per bucket (L2LDS::flo)
+struct FlatSrc {
+  const uint32_t *cnt;  // [F][nbo] records of bucket (b_lo + i) in flat source f
+  const uint64_t *at;   // [F][nbo] device address of the first of them
+  uint32_t F, nbo;      // flat sources so far; buckets this shard owns
+  uint32_t b_lo, b_hi;  // ... which are these
+};
+
 enum {  // counters of this path, one u64 each
   CB_OVF1 = 0, CB_OVF2, CB_FATAL, CB_FLAGGED_RECS, CB_DUMP, CB_ENTRIES, CB_OUT_RESERVED, CB_COUNT = 16
 };
@@ -814,13 +824,15 @@ __device__ __forceinline__ const uint32_t *l2_record32(const Geom &gm, const Buc
 
 // ---- between the levels: every bucket gets a private, exactly sized part of the level-2 arena ---------
 // chunks(b) = ceil(records(b) / CH2) + P2: each of its P2 regions wastes less than one chunk
-__global__ __launch_bounds__(WGB) void kc_bucket_prefix_kernel(Geom gm, BucketBufs bb, uint64_t *cb) {
+__global__ __launch_bounds__(WGB) void kc_bucket_prefix_kernel(Geom gm, BucketBufs bb, FlatSrc fs, uint64_t *cb) {
   __shared__ ScanLDS S;
   const uint32_t b = threadIdx.x;
   uint32_t chunks = 0;
   if (b < gm.P1) {
     uint64_t n = 0;
     for (uint32_t g = 0; g < gm.G; g++) n += bb.cnt1[(size_t)g * gm.P1 + b];
+    if (b >= fs.b_lo && b < fs.b_hi)
+      for (uint32_t f = 0; f < fs.F; f++) n += fs.cnt[(size_t)f * fs.nbo + (b - fs.b_lo)];
     chunks = (uint32_t)((n + (1u << gm.log2CH2) - 1) >> gm.log2CH2) + gm.P2;
   }
   const uint32_t e = block_excl_scan(chunks, S);
@@ -834,15 +846,18 @@ __global__ __launch_bounds__(WGB) void kc_bucket_prefix_kernel(Geom gm, BucketBu
 // ---- level 2 ------------------------------------------------------------------------------------------
 struct L2LDS {
   SplitLDS sp;
-  uint32_t pre[GMAX + 1];  // prefix of the bucket's G segment lengths
+  uint32_t pre[GMAX + 1];  // prefix of the bucket's G segment lengths (+ those of its flat sources)
   uint32_t idle[64];       // what the lanes past the end add to (one word per lane)
+  uint64_t flo[FLAT_MAX];  // shard flow: where the bucket's run starts in each flat source
 };
 
 // CP: the records are mixed ones; what leaves for the regions is their 32-bit remainder (cp_pack32)
 // CR: compact records whose mix fits 32 bits below the bucket (2k - la <= 32) are kept in the short register form of
 // split_stage between the rounds (half the registers of the full records)
-template <int NL, bool CP, bool CR>
-__global__ __launch_bounds__(WGB) void kc_l2_split_kernel(Geom gm, BucketBufs bb, uint64_t *cb) {
+// FL: the shard flow -- only the buckets [fs.b_lo, fs.b_hi) are this shard's, and a bucket's records are its G chains
+// followed by fs.F flat sources (G + fs.F <= GMAX)
+template <int NL, bool CP, bool CR, bool FL>
+__global__ __launch_bounds__(WGB) void kc_l2_split_kernel(Geom gm, BucketBufs bb, FlatSrc fs, uint64_t *cb) {
   static_assert(!CR || (CP && NL == 1), "the short form is one of compact records");
   extern __shared__ __align__(16) uint8_t smem[];
   L2LDS &L = *reinterpret_cast<L2LDS *>(smem);
@@ -851,13 +866,20 @@ __global__ __launch_bounds__(WGB) void kc_l2_split_kernel(Geom gm, BucketBufs bb
   const int tid = threadIdx.x;
   const uint32_t P1 = gm.P1, P2 = gm.P2, G = gm.G;
   if (tid < 64) L.idle[tid] = 0;
-  for (uint32_t b1 = blockIdx.x; b1 < P1; b1 += gridDim.x) {
-    // prefix over the G segments of this bucket
+  const uint32_t GT = FL ? G + fs.F : G;  // segments of a bucket
+  for (uint32_t b1 = (FL ? fs.b_lo : 0u) + blockIdx.x; b1 < (FL ? fs.b_hi : P1); b1 += gridDim.x) {
+    // prefix over the segments of this bucket
     {
-      const uint32_t v = ((uint32_t)tid < G) ? bb.cnt1[(size_t)tid * P1 + b1] : 0u;
+      uint32_t v = ((uint32_t)tid < G) ? bb.cnt1[(size_t)tid * P1 + b1] : 0u;
+      if constexpr (FL) {
+        if ((uint32_t)tid >= G && (uint32_t)tid < GT) {
+          v = fs.cnt[(size_t)(tid - G) * fs.nbo + (b1 - fs.b_lo)];
+          L.flo[tid - G] = fs.at[(size_t)(tid - G) * fs.nbo + (b1 - fs.b_lo)];
+        }
+      }
       const uint32_t e = block_excl_scan(v, L.sp.scan);
-      if ((uint32_t)tid < G) L.pre[tid] = e;
-      if (tid == 0) L.pre[G] = L.sp.scan.total;
+      if ((uint32_t)tid < GT) L.pre[tid] = e;
+      if (tid == 0) L.pre[GT] = L.sp.scan.total;
     }
     ChainDest D;
     D.arena = bb.rec2;
@@ -873,7 +895,7 @@ __global__ __launch_bounds__(WGB) void kc_l2_split_kernel(Geom gm, BucketBufs bb
 #endif
     ChainState cst = split_load_state(L.sp, P2, nullptr, D.chain, D.LMAX, D.log2CH, 0);
     __syncthreads();
-    const uint32_t n = L.pre[G];
+    const uint32_t n = L.pre[GT];
     const uint32_t per_round = WGB * RPOS;
     // The records of the next round travel while this round is split.  A record's address needs its chunk id, which
     // is itself in memory (chain1): all ids of a round are requested first and all records after them, two memory
@@ -889,13 +911,19 @@ __global__ __launch_bounds__(WGB) void kc_l2_split_kernel(Geom gm, BucketBufs bb
       for (int j = 0; j < RPOS; j++) {
         const uint32_t e = min(v0 + (uint32_t)j * WGB + tid, n - 1u);
         while (e >= L.pre[p_ids + 1]) p_ids++;
-        ids[j] = bb.chain1[((size_t)p_ids * gm.P1 + b1) * gm.L1MAX + ((e - L.pre[p_ids]) >> gm.log2CH1)];
+        // (a record of a flat source needs no chunk id: it re-reads the table's first word, no branch)
+        const size_t ci = ((size_t)p_ids * gm.P1 + b1) * gm.L1MAX + ((e - L.pre[p_ids]) >> gm.log2CH1);
+        ids[j] = bb.chain1[FL && p_ids >= G ? 0 : ci];
       }
 #pragma unroll
       for (int j = 0; j < RPOS; j++) {
         const uint32_t e = min(v0 + (uint32_t)j * WGB + tid, n - 1u);
         while (e >= L.pre[p_rec + 1]) p_rec++;
         const uint64_t *src = bb.rec1 + (((((size_t)p_rec * gm.A1) + ids[j]) << gm.log2CH1) + ((e - L.pre[p_rec]) & CH1m)) * NL;
+        if constexpr (FL) {
+          const uint64_t f0 = L.flo[p_rec >= G ? p_rec - G : 0u];
+          if (p_rec >= G) src = reinterpret_cast<const uint64_t *>((uintptr_t)f0) + (size_t)(e - L.pre[p_rec]) * NL;
+        }
 #pragma unroll
         for (int w = 0; w < NL; w++) nxt[j][w] = src[w];
       }

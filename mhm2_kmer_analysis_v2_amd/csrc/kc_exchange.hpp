@@ -2,19 +2,27 @@
 //
 // Replaces the reference's only bulk exchange inside the node: the aggregated RPC of
 // ThreeTierAggrStore<Supermer>::update / flush_updates (src/kcount/kmer_dht.cpp:143-151,247-258) that carries every
-// supermer to the rank owning its k-mers.  One process per GPU, one ShardExchange per process:
+// supermer to the rank owning its k-mers.  One process per GPU, one ShardExchange per process.  Two flows:
 //
-//   per block of reads   kc_extract_partition          records binned by owner shard (compute stream)
-//                        ncclAllGather of the counts   N x N u64: everybody learns what it will receive
-//                        grouped ncclSend / ncclRecv   all-to-all-v of the records on a SIDE stream, so that it
-//                                                      overlaps the extraction of the next block
-//                        kc_insert_records             the rank's own share straight from its send buffer, what arrived
-//                                                      from the others once the side stream says so (an event, no host wait)
+//   BUCKETS (default): the single-pass shard flow of csrc/kc_shard.hpp -- a shard owns level-1 buckets
+//     per block of reads   kc_shard_extract              the block through level 1; what other shards own packed into
+//                                                        one wire segment per destination (compute stream)
+//                          ncclAllGather of the sizes    N x N u64: everybody learns what it will receive
+//                          kc_shard_reserve              room for it inside the receiving context (it stays there)
+//                          grouped ncclSend / ncclRecv   all-to-all-v of the segments on a SIDE stream, so that it
+//                                                        overlaps the extraction of the next block
+//                          kc_shard_commit               per received segment, once the side stream says it has landed
+//                                                        (an event, no host wait on the transfer): read in place by level 2
+//     the rank's own share never moves at all.
+//   RECORDS: k-mer records binned by hash owner (kc_extract_partition), inserted by the receiver's level 1
+//     (kc_insert_records) -- two more passes over every record, but it also works for a context on the global-table path
+//     and its records are what a upcxx::rpc would carry across nodes.
 //
-// Two send and two receive buffers alternate, so block i travels while block i-1 is inserted and block i+1 extracted.
-// Nothing else is communicated: ownership is a pure function of the k-mer (kc_owner), finalize is per shard.
-// xGMI is point to point: every rank ships 1/N of its records to each peer over that peer's own link, a few GB/s per
-// link at the rates the kernels reach -- far below a link's ~150 GB/s, so the exchange hides behind the extraction.
+// Two send buffers alternate, so block i travels while block i+1 is extracted.  Nothing else is communicated: ownership
+// is a pure function of the k-mer (kc_shard_owner / kc_owner), finalize is per shard.
+// xGMI is point to point: every rank ships 1/N of its records to each peer over that peer's own link; at 8 bytes per
+// k-mer and the rate one GPU extracts at (~45 G k-mers/s) that is ~45 GB/s per link, within a link's ~75 GB/s per
+// direction but not negligible -- hence the side stream.
 //
 // Header-only over the C ABI (include/kcount_mi355.h) and <rccl/rccl.h>; no exceptions (MHM2 calls this inside UPC++
 // progress): every method returns a KC_* status, last_error() has the text.  The Python twin used by bench.py and the
@@ -33,21 +41,32 @@
 namespace kcount_mi355 {
 
 class ShardExchange {
+ public:
+  enum Flow { BUCKETS = 0, RECORDS = 1 };
+
+ private:
   kc_ctx *ctx;
   ncclComm_t comm;
   int me, n, nl;
-  uint64_t seg;                    // records per destination segment of a send buffer
+  uint64_t seg;                    // BUCKETS: words, RECORDS: records per destination segment of a send buffer
+  Flow flow;
   hipStream_t compute = nullptr;   // the context's stream (ours unless the caller gave one)
   hipStream_t side = nullptr;      // RCCL's stream
   bool own_compute = false;
-  uint64_t *send[2] = {nullptr, nullptr}, *recv[2] = {nullptr, nullptr};
+  uint64_t *send[2] = {nullptr, nullptr}, *recv[2] = {nullptr, nullptr};  // recv[]: RECORDS only
   uint64_t recv_cap[2] = {0, 0};
-  uint64_t *d_counts = nullptr, *d_all = nullptr;  // this rank's N counts; everybody's N x N
+  uint64_t *d_counts = nullptr, *d_all = nullptr;  // this rank's N sizes; everybody's N x N
   uint64_t *h_all = nullptr;                       // pinned
-  hipEvent_t arrived[2] = {nullptr, nullptr};      // side stream: block's records have landed in recv[i]
-  hipEvent_t consumed[2] = {nullptr, nullptr};     // compute stream: the inserts reading send[i] / recv[i] are done
+  hipEvent_t arrived[2] = {nullptr, nullptr};      // side stream: the block has landed
+  hipEvent_t consumed[2] = {nullptr, nullptr};     // compute stream: whatever read send[i] / recv[i] is done
   bool used[2] = {false, false};
-  struct Pending { bool any = false; int buf = 0; uint64_t n_own = 0, n_recv = 0; } pending;
+  struct Piece { const uint64_t *p; uint64_t words; };
+  struct Pending {
+    bool any = false;
+    int buf = 0;
+    uint64_t n_own = 0, n_recv = 0;  // RECORDS
+    std::vector<Piece> pieces;       // BUCKETS: the received segments, where they landed
+  } pending;
   uint64_t blocks = 0, sent = 0, received = 0;
   std::string err;
 
@@ -71,29 +90,39 @@ class ShardExchange {
     if (s_ != KC_OK) return fail(s_, #call, kc_last_error());                          \
   } while (0)
 
-  // the previous block: its own share and what it received go into the table (compute stream, ordered by events)
+  // the previous block: what it received joins the table (compute stream, ordered behind the transfer by an event)
   int complete() {
     if (!pending.any) return KC_OK;
     const int b = pending.buf;
-    if (pending.n_own) KCX_KC(kc_insert_records(ctx, send[b] + (uint64_t)me * seg * nl, pending.n_own));
-    if (pending.n_recv) {
-      KCX_HIP(hipStreamWaitEvent(compute, arrived[b], 0));
-      KCX_KC(kc_insert_records(ctx, recv[b], pending.n_recv));
+    if (flow == BUCKETS) {
+      if (!pending.pieces.empty()) KCX_HIP(hipStreamWaitEvent(compute, arrived[b], 0));
+      for (const Piece &pc : pending.pieces) {
+        KCX_KC(kc_shard_commit(ctx, pc.p, pc.words));
+        received += pc.words;
+      }
+      pending.pieces.clear();
+    } else {
+      if (pending.n_own) KCX_KC(kc_insert_records(ctx, send[b] + (uint64_t)me * seg * nl, pending.n_own));
+      if (pending.n_recv) {
+        KCX_HIP(hipStreamWaitEvent(compute, arrived[b], 0));
+        KCX_KC(kc_insert_records(ctx, recv[b], pending.n_recv));
+      }
+      KCX_HIP(hipEventRecord(consumed[b], compute));
+      received += pending.n_own + pending.n_recv;
     }
-    KCX_HIP(hipEventRecord(consumed[b], compute));
-    received += pending.n_own + pending.n_recv;
     pending.any = false;
     return KC_OK;
   }
 
  public:
-  // ctx: this rank's context (created with the same rank_me / rank_n as `comm`); num_longs: words of a record on the
-  // wire, kc_record_longs(k); seg_capacity: records one block may
-  // send to one shard (a block of R reads of length L needs about R * (L - k - 1) / rank_n * 1.25);
-  // compute_stream: the stream the context's kernels should run on, NULL = a stream of this object's own.
+  // ctx: this rank's context (created with the same rank_me / rank_n as `comm`, and -- BUCKETS -- the same sizes and
+  // tuning on every rank); num_longs: kc_record_longs(k); seg_capacity: what one block may send to one shard, in WORDS
+  // for BUCKETS (a block of R reads of length L needs about R * (L - k - 1) / rank_n * num_longs * 1.1 + 1024), in
+  // RECORDS for RECORDS (R * (L - k - 1) / rank_n * 1.25); compute_stream: the stream the context's kernels should run
+  // on, NULL = a stream of this object's own.
   ShardExchange(kc_ctx *ctx_, ncclComm_t comm_, int rank_me, int rank_n, int num_longs, uint64_t seg_capacity,
-                hipStream_t compute_stream = nullptr)
-      : ctx(ctx_), comm(comm_), me(rank_me), n(rank_n), nl(num_longs), seg(seg_capacity), compute(compute_stream) {}
+                hipStream_t compute_stream = nullptr, Flow flow_ = BUCKETS)
+      : ctx(ctx_), comm(comm_), me(rank_me), n(rank_n), nl(num_longs), seg(seg_capacity), flow(flow_), compute(compute_stream) {}
   ShardExchange(const ShardExchange &) = delete;
   ShardExchange &operator=(const ShardExchange &) = delete;
 
@@ -106,7 +135,7 @@ class ShardExchange {
     KCX_KC(kc_set_stream(ctx, (void *)compute));
     KCX_HIP(hipStreamCreateWithFlags(&side, hipStreamNonBlocking));
     for (int b = 0; b < 2; b++) {
-      KCX_HIP(hipMalloc((void **)&send[b], (size_t)n * seg * nl * 8));
+      KCX_HIP(hipMalloc((void **)&send[b], (size_t)n * seg * (flow == BUCKETS ? 1 : nl) * 8));
       KCX_HIP(hipEventCreateWithFlags(&arrived[b], hipEventDisableTiming));
       KCX_HIP(hipEventCreateWithFlags(&consumed[b], hipEventDisableTiming));
     }
@@ -135,58 +164,77 @@ class ShardExchange {
     }
   }
 
-  // count_kmers' loop body for one block of reads (src/kcount/kcount.cpp:71-90 + kmer_dht.cpp:247-250): extract, bin,
-  // ship.  bases / quals / offsets as for kc_extract_partition.  Collective: every rank calls it the same number of
-  // times (a rank that has run out of reads calls it with nreads = 0).
+  // count_kmers' loop body for one block of reads (src/kcount/kcount.cpp:71-90 + kmer_dht.cpp:247-250): extract, ship.
+  // bases / quals / offsets as for kc_submit_reads.  Collective: every rank calls it the same number of times (a rank
+  // that has run out of reads calls it with nreads = 0).
   int add_block(const uint8_t *bases, const uint8_t *quals, const uint64_t *offsets, uint64_t nreads, int on_device) {
     const int b = (int)(blocks & 1);
     blocks++;
-    // send[b] / recv[b] were last read by the inserts of two blocks ago: the extraction below is ordered behind them by
-    // the compute stream itself, the transfers of this block by the event
+    // send[b] was last read by the transfers of two blocks ago (BUCKETS) or by the inserts of its own share (RECORDS)
+    if (used[b]) {
+      if (flow == BUCKETS) KCX_HIP(hipEventSynchronize(arrived[b]));  // the kernels below overwrite it at once
+      // RECORDS: the extraction is ordered behind those inserts by the compute stream itself
+    }
     std::vector<uint64_t> counts((size_t)n, 0);
-    if (nreads) KCX_KC(kc_extract_partition(ctx, bases, quals, offsets, nreads, on_device, send[b], seg, counts.data()));
-    // everybody's counts: N x N, row s = what rank s sends to each shard
+    if (flow == BUCKETS) {
+      KCX_KC(kc_shard_extract(ctx, bases, quals, offsets, nreads, on_device, send[b], seg, counts.data()));
+    } else if (nreads) {
+      KCX_KC(kc_extract_partition(ctx, bases, quals, offsets, nreads, on_device, send[b], seg, counts.data()));
+    }
+    // everybody's sizes: N x N, row s = what rank s sends to each shard
     KCX_HIP(hipMemcpyAsync(d_counts, counts.data(), (size_t)n * 8, hipMemcpyHostToDevice, side));
     KCX_NCCL(ncclAllGather(d_counts, d_all, (size_t)n, ncclUint64, comm, side));
     KCX_HIP(hipMemcpyAsync(h_all, d_all, (size_t)n * n * 8, hipMemcpyDeviceToHost, side));
     KCX_HIP(hipStreamSynchronize(side));
-    uint64_t total = 0;
+    const uint64_t unit = flow == BUCKETS ? 1 : (uint64_t)nl;  // words per counted thing
+    uint64_t total = 0;  // BUCKETS: every sender's part starts on a 16-byte boundary
     for (int s = 0; s < n; s++)
-      if (s != me) total += h_all[(size_t)s * n + me];
-    if (total > recv_cap[b]) {
-      if (used[b]) KCX_HIP(hipEventSynchronize(consumed[b]));
-      if (recv[b]) KCX_HIP(hipFree(recv[b]));
-      recv[b] = nullptr;
-      recv_cap[b] = total + total / 8 + 1024;
-      KCX_HIP(hipMalloc((void **)&recv[b], (size_t)recv_cap[b] * nl * 8));
+      if (s != me) total += flow == BUCKETS ? ((h_all[(size_t)s * n + me] + 1) & ~1ULL) : h_all[(size_t)s * n + me];
+    uint64_t *dst = nullptr;
+    if (flow == BUCKETS) {
+      KCX_KC(kc_shard_reserve(ctx, total, &dst));  // inside the context, for good: level 2 reads it in place
+    } else {
+      if (total > recv_cap[b]) {
+        if (used[b]) KCX_HIP(hipEventSynchronize(consumed[b]));
+        if (recv[b]) KCX_HIP(hipFree(recv[b]));
+        recv[b] = nullptr;
+        recv_cap[b] = total + total / 8 + 1024;
+        KCX_HIP(hipMalloc((void **)&recv[b], (size_t)recv_cap[b] * nl * 8));
+      }
+      dst = recv[b];
     }
     // the previous block: its transfer has had this block's extraction to finish
     int rc = complete();
     if (rc) return rc;
-    // all-to-all-v of the records: one group of point-to-point transfers (each pair has its own xGMI link)
-    if (used[b]) KCX_HIP(hipStreamWaitEvent(side, consumed[b], 0));
+    // all-to-all-v: one group of point-to-point transfers (each pair has its own xGMI link)
+    if (flow == RECORDS && used[b]) KCX_HIP(hipStreamWaitEvent(side, consumed[b], 0));
     KCX_NCCL(ncclGroupStart());
     uint64_t pos = 0;
     for (int d = 0; d < n; d++) {
       if (d == me) continue;  // this rank's own share never travels
       const uint64_t sc = counts[(size_t)d], rcv = h_all[(size_t)d * n + me];
-      if (rcv) KCX_NCCL(ncclRecv(recv[b] + pos * nl, (size_t)rcv * nl, ncclUint64, d, comm, side));
-      if (sc) KCX_NCCL(ncclSend(send[b] + (uint64_t)d * seg * nl, (size_t)sc * nl, ncclUint64, d, comm, side));
-      pos += rcv;
+      if (rcv) {
+        KCX_NCCL(ncclRecv(dst + pos * unit, (size_t)rcv * unit, ncclUint64, d, comm, side));
+        if (flow == BUCKETS) pending.pieces.push_back(Piece{dst + pos, rcv});
+      }
+      if (sc) KCX_NCCL(ncclSend(send[b] + (uint64_t)d * seg * unit, (size_t)sc * unit, ncclUint64, d, comm, side));
+      pos += flow == BUCKETS ? ((rcv + 1) & ~1ULL) : rcv;
       sent += sc;
     }
     KCX_NCCL(ncclGroupEnd());
     KCX_HIP(hipEventRecord(arrived[b], side));
     used[b] = true;
-    sent += counts[(size_t)me];
     pending.any = true;
     pending.buf = b;
-    pending.n_own = counts[(size_t)me];
-    pending.n_recv = total;
+    if (flow == RECORDS) {
+      sent += counts[(size_t)me];
+      pending.n_own = counts[(size_t)me];
+      pending.n_recv = total;
+    }
     return KC_OK;
   }
 
-  // KmerDHT::flush_updates (kmer_dht.cpp:252-258): the last block in flight is inserted; call before kc_finalize
+  // KmerDHT::flush_updates (kmer_dht.cpp:252-258): the last block in flight joins the table; call before kc_finalize
   int finish() {
     int rc = complete();
     if (rc) return rc;
@@ -194,8 +242,11 @@ class ShardExchange {
     return KC_OK;
   }
 
-  uint64_t records_sent() const { return sent; }          // this rank's records, its own share included
-  uint64_t records_received() const { return received; }  // records inserted into this rank's table
+  // BUCKETS: words shipped to / received from other ranks; RECORDS: records, the rank's own share included
+  uint64_t sent_units() const { return sent; }
+  uint64_t received_units() const { return received; }
+  uint64_t records_sent() const { return sent; }
+  uint64_t records_received() const { return received; }
   const char *last_error() const { return err.c_str(); }
   hipStream_t compute_stream() const { return compute; }
 #undef KCX_HIP

@@ -3,11 +3,17 @@
 
 Replaces the reference's only bulk exchange, the aggregated UPC++ RPC of
 ThreeTierAggrStore::update (src/kcount/kmer_dht.cpp:143-151,247-258), inside the
-node: per block of reads every rank bins its k-mer records by owner shard
-(kc_extract_partition), the ranks swap the per-shard counts (an N x N all-to-all of
-int64), then the records themselves (all-to-all-v as grouped send/recv), and each
-rank inserts what it received (kc_insert_records).  Nothing else is communicated:
-ownership is a pure function of the k-mer, finalize is per shard.
+node.  Two flows, one protocol (sizes first, then one group of point-to-point transfers):
+
+  single pass (ShardedKmerAnalysis.single_pass, what bench.py runs): a shard owns level-1 BUCKETS (csrc/kc_shard.hpp).
+      Per block of reads every rank runs its ordinary level-1 pass and packs what other shards own into one wire
+      segment per destination (kc_shard_extract); the ranks swap the segment sizes (an N x N all-to-all of int64), then
+      the segments, each landing in memory of the receiving context (kc_shard_reserve) where level 2 later reads it in
+      place (kc_shard_commit).  A rank's own share never moves.
+  records: k-mer records binned by hash owner (kc_extract_partition), inserted by the receiver's level 1
+      (kc_insert_records): two more passes over every record, but independent of the bucketed path.
+
+Nothing else is communicated: ownership is a pure function of the k-mer, finalize is per shard.
 """
 import torch
 import torch.distributed as dist
@@ -20,37 +26,46 @@ def exchange_counts(send_counts, group=None):
     return recv
 
 
-def start_exchange(send, send_counts, recv_counts, seg_capacity, num_longs, recv=None, group=None):
-    """Begin the all-to-all-v of one block.  send: int64 tensor laid out as world segments of seg_capacity records
-    (num_longs words each), the first send_counts[d] records of segment d being valid.  Returns
-    (works, recv tensor, n_received): the records received from the OTHER ranks packed back to back once every work
-    has been waited for.  The rank's own share stays where it is: local_share(send, send_counts, ...) is its view."""
+def start_exchange(send, send_counts, recv_counts, seg_capacity, num_longs, recv=None, group=None, reserve=None):
+    """Begin the all-to-all-v of one block.  send: int64 tensor laid out as world segments of seg_capacity units
+    (num_longs words each), the first send_counts[d] units of segment d being valid.  Returns
+    (works, recv tensor, n_received, pieces): what the OTHER ranks sent, once every work has been waited for; pieces =
+    [(first word, words)] per sender.  Without `reserve` the parts are packed back to back in `recv` (grown as needed);
+    with it (the single-pass flow: reserve(nwords) -> tensor inside the receiving context) every part starts on a
+    16-byte boundary of a fresh reservation.  The rank's own share stays where it is: local_share(...) is its view."""
     world = dist.get_world_size(group)
+    me = dist.get_rank(group)
     sc = [int(x) for x in send_counts.tolist()]
     rc = [int(x) for x in recv_counts.tolist()]
-    total = sum(rc) - rc[dist.get_rank(group)]  # what arrives from the other ranks
-    if recv is None or recv.numel() < max(total, 1) * num_longs:
-        recv = torch.empty(max(total, 1) * num_longs, dtype=send.dtype, device=send.device)
+    align = 2 if reserve is not None else 1
+    starts, pos = [], 0
+    for d in range(world):
+        starts.append(pos)
+        if d != me:
+            pos += (rc[d] * num_longs + align - 1) // align * align
+    total = sum(rc) - rc[me]  # what arrives from the other ranks
+    if reserve is not None:
+        recv = reserve(pos)
+    elif recv is None or recv.numel() < max(pos, 1):
+        recv = torch.empty(max(pos, 1), dtype=send.dtype, device=send.device)
     # all-to-all-v as one group of point-to-point transfers (RCCL: a single ncclGroup of
     # ncclSend/ncclRecv over xGMI; gloo: the same ops over TCP).  The segments of `send` are not
     # contiguous, so a single-buffer all_to_all_single would need an extra packing pass over HBM.
-    me = dist.get_rank(group)
-    ops = []
-    pos = 0
+    ops, pieces = [], []
     for d in range(world):
+        if d == me:
+            continue  # this rank's own share never travels
         base = d * seg_capacity * num_longs
         src = send[base:base + sc[d] * num_longs]
-        if d == me:
-            continue  # this rank's own share never travels: the caller inserts it straight from `send` (local_share)
-        dst = recv[pos:pos + rc[d] * num_longs]
-        pos += rc[d] * num_longs
+        dst = recv[starts[d]:starts[d] + rc[d] * num_longs]
         peer = dist.get_global_rank(group, d) if group is not None else d
         if rc[d]:
             ops.append(dist.P2POp(dist.irecv, dst, peer, group))
+            pieces.append((starts[d], rc[d] * num_longs))
         if sc[d]:
             ops.append(dist.P2POp(dist.isend, src, peer, group))
     works = dist.batch_isend_irecv(ops) if ops else []
-    return works, recv, total
+    return works, recv, total, pieces
 
 
 def local_share(send, send_counts, seg_capacity, num_longs, group=None):
@@ -63,7 +78,7 @@ def local_share(send, send_counts, seg_capacity, num_longs, group=None):
 
 def exchange_records(send, send_counts, recv_counts, seg_capacity, num_longs, recv=None, group=None):
     """Blocking form of start_exchange: returns (received from the others, their number, own share, its number)."""
-    works, recv, total = start_exchange(send, send_counts, recv_counts, seg_capacity, num_longs, recv, group)
+    works, recv, total, _ = start_exchange(send, send_counts, recv_counts, seg_capacity, num_longs, recv, group)
     for w in works:
         w.wait()
     own, n_own = local_share(send, send_counts, seg_capacity, num_longs, group)
@@ -72,20 +87,24 @@ def exchange_records(send, send_counts, recv_counts, seg_capacity, num_longs, re
 
 class ShardedKmerAnalysis:
     """count_kmers + flush_updates + finish_updates (src/kcount/kcount.cpp:54-104,142-161) across the ranks
-    of one node.  `extract(block, send, seg_capacity) -> counts` and `insert(recv, n)` are the two device
-    entry points (KmerCounter.extract_partition / insert_records on the GPU; the CPU tests plug in stand-ins
-    so that the exchange logic itself is what they exercise).
+    of one node.
 
-    Two send and two receive buffers: while block i travels (RCCL's own stream), block i-1 is inserted and
-    block i+1 is extracted on the compute stream.
+    Records flow: `extract(block, send, seg_capacity) -> counts` and `insert(recv, n)` are the two device entry points
+    (KmerCounter.extract_partition / insert_records).  Single-pass flow (`reserve` given, see single_pass()):
+    `extract(block, send, seg_words) -> words per destination` (KmerCounter.shard_extract), `reserve(nwords) -> tensor`
+    (KmerCounter.shard_reserve) and `insert(segment, nwords)` (KmerCounter.shard_commit), num_longs = 1.  The CPU tests
+    plug in stand-ins, so that the exchange logic itself is what they exercise.
+
+    Two send buffers (and, records flow, two receive buffers): while block i travels (RCCL's own stream), block i-1 joins
+    the table and block i+1 is extracted on the compute stream.
 
     Stream rule (GPU): a finished RCCL work orders only torch's CURRENT stream behind the transfer, so the library's
     kernels must run on that stream or they could read `recv` before it has landed.  Pass the KmerCounter as
     `counter` and this class puts it on torch's current stream of `device` (kc_set_stream); without one the caller
     must have done so itself.  The C++ twin (csrc/kc_exchange.hpp) orders its two streams with events instead."""
 
-    def __init__(self, extract, insert, num_longs, seg_capacity, device, group=None, counter=None):
-        self.extract, self.insert = extract, insert
+    def __init__(self, extract, insert, num_longs, seg_capacity, device, group=None, counter=None, reserve=None):
+        self.extract, self.insert, self.reserve = extract, insert, reserve
         self.nl, self.seg = num_longs, seg_capacity
         self.group = group
         self.world = dist.get_world_size(group)
@@ -105,16 +124,24 @@ class ShardedKmerAnalysis:
         self.sent = 0
         self.received = 0
 
+    @classmethod
+    def single_pass(cls, counter, extract, seg_words, device, group=None):
+        """The single-pass flow over a KmerCounter: extract(block, send, seg_words) must call counter.shard_extract."""
+        return cls(extract, counter.shard_commit, 1, seg_words, device, group, counter, reserve=counter.shard_reserve)
+
     def _complete(self):
         if self.pending is None:
             return 0
-        works, recv, n, own, n_own = self.pending
+        works, recv, n, own, n_own, pieces = self.pending
         self.pending = None
         if n_own:
             self.insert(own, n_own)  # straight from the send buffer (reused two blocks later at the earliest)
         for w in works:
             w.wait()
-        if n:
+        if self.reserve is not None:
+            for first, words in pieces:  # every received segment joins its buckets where it lies
+                self.insert(recv[first:first + words], words)
+        elif n:
             self.insert(recv, n)
         self.received += n + n_own
         return n + n_own
@@ -122,13 +149,16 @@ class ShardedKmerAnalysis:
     def add_block(self, block):
         b = self.i % 2
         self.i += 1
+        # send[b] is free: its last transfer (two blocks ago) was waited for when the block after it was added
         counts = self.extract(block, self.send[b], self.seg)
         sc_host = torch.as_tensor([int(c) for c in counts], dtype=torch.int64)
         rc = exchange_counts(sc_host.to(self.device), self.group).cpu()  # the one host round trip of a block
-        works, self.recv[b], n = start_exchange(self.send[b], sc_host, rc, self.seg, self.nl, self.recv[b], self.group)
-        own, n_own = local_share(self.send[b], sc_host, self.seg, self.nl, self.group)
+        works, recv, n, pieces = start_exchange(self.send[b], sc_host, rc, self.seg, self.nl, self.recv[b], self.group, self.reserve)
+        if self.reserve is None:
+            self.recv[b] = recv
+        own, n_own = (None, 0) if self.reserve is not None else local_share(self.send[b], sc_host, self.seg, self.nl, self.group)
         self._complete()  # the previous block: its transfer has had this block's extraction to finish
-        self.pending = (works, self.recv[b], n, own, n_own)
+        self.pending = (works, recv, n, own, n_own, pieces)
         self.sent += int(sc_host.sum())
         return n + n_own
 

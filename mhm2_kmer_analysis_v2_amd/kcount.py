@@ -28,6 +28,18 @@ def _ptr(a):
     return a.ctypes.data, False
 
 
+class _DeviceWords:
+    """Raw device memory of the library as something torch can view without a copy (__cuda_array_interface__)."""
+
+    def __init__(self, ptr, nwords, device):
+        self.__cuda_array_interface__ = {"shape": (nwords,), "typestr": "<i8", "data": (ptr, False), "version": 2}
+        self.device = device
+
+    def tensor(self):
+        import torch
+        return torch.as_tensor(self, device=self.device)
+
+
 def synth_params(**kw):
     p = kc_synth_params()
     lib().kc_synth_default_params(C.byref(p))
@@ -54,10 +66,10 @@ class KmerCounter:
     """One shard (one GPU) of the k-mer analysis stage."""
 
     def __init__(self, kmer_len, qual_offset=33, dmin_thres=2, device=0, rank_me=0, rank_n=1, max_elems=0, time_kernels=False,
-                 max_kmers_buffered=0, tuning=None, reference_owner=False):
+                 max_kmers_buffered=0, tuning=None, reference_owner=False, shard_buckets=False):
         L = lib()
         cfg = kc_config(kmer_len=kmer_len, qual_offset=qual_offset, dmin_thres=dmin_thres, device=device, rank_me=rank_me,
-                        rank_n=rank_n, max_elems=max_elems, flags=(_lib.KC_FLAG_TIME_KERNELS if time_kernels else 0) | (_lib.KC_FLAG_REFERENCE_OWNER if reference_owner else 0),
+                        rank_n=rank_n, max_elems=max_elems, flags=(_lib.KC_FLAG_TIME_KERNELS if time_kernels else 0) | (_lib.KC_FLAG_REFERENCE_OWNER if reference_owner else 0) | (_lib.KC_FLAG_SHARD_BUCKETS if shard_buckets else 0),
                         reserved=0,
                         max_kmers_buffered=max_kmers_buffered)
         st = C.c_int(0)
@@ -68,6 +80,7 @@ class KmerCounter:
         self.nl = L.kc_num_longs(kmer_len)          # words of a k-mer in results, dumps and lookups (the reference's)
         self.rec_nl = L.kc_record_longs(kmer_len)   # words of a record on the shard wire (extract_partition / insert_records)
         self.rank_me, self.rank_n = rank_me, rank_n
+        self.device = device
         self._tuning = tuning
         if tuning:
             self.set_tuning(**tuning)
@@ -168,6 +181,43 @@ class KmerCounter:
     def insert_records(self, records, n):
         pr, _ = _ptr(records)
         check(lib().kc_insert_records(self._h, pr, n), "kc_insert_records")
+
+    # ---- the single-pass shard flow (ownership by level-1 bucket) ----
+    def shard_extract(self, bases, quals, offsets, segments, seg_words, nreads=None):
+        """segments: device buffer of rank_n*seg_words u64.  Returns the words to ship per destination."""
+        pb, dev = _ptr(bases)
+        pq, _ = _ptr(quals)
+        po, _ = _ptr(offsets)
+        ps, _ = _ptr(segments)
+        n = (len(offsets) - 1) if nreads is None else nreads
+        words = np.zeros(self.rank_n, dtype=np.uint64)
+        check(lib().kc_shard_extract(self._h, pb, pq, po, n, 1 if dev else 0, ps, seg_words, words.ctypes.data), "kc_shard_extract")
+        return words
+
+    def shard_reserve(self, nwords, device=None):
+        """Context-owned device memory for nwords incoming u64, as an int64 torch tensor viewing it (no copy)."""
+        import torch
+        p = C.c_void_p(0)
+        check(lib().kc_shard_reserve(self._h, int(nwords), C.byref(p)), "kc_shard_reserve")
+        if not nwords:
+            return torch.empty(0, dtype=torch.int64, device=device or ("cuda:%d" % self.device))
+        return _DeviceWords(p.value, int(nwords), device or ("cuda:%d" % self.device)).tensor()
+
+    def shard_commit(self, segment, nwords):
+        ps, _ = _ptr(segment)
+        check(lib().kc_shard_commit(self._h, ps, int(nwords)), "kc_shard_commit")
+
+    def shard_capacity(self):
+        """Distinct k-mers this shard's regions hold in the single-pass flow (kc_shard_capacity)."""
+        v = C.c_uint64(0)
+        check(lib().kc_shard_capacity(self._h, C.byref(v)), "kc_shard_capacity")
+        return v.value
+
+    def shard_owner(self, kmer_words):
+        w = np.ascontiguousarray(kmer_words, dtype=np.uint64)
+        o = C.c_int(-1)
+        check(lib().kc_shard_owner(self._h, w.ctypes.data, C.byref(o)), "kc_shard_owner")
+        return o.value
 
     def flush(self):
         check(lib().kc_flush(self._h), "kc_flush")

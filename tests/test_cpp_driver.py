@@ -39,15 +39,18 @@ def test_rccl_exchange_compiles_and_links(tmp_path):
 
 
 @pytest.mark.gpu
+@pytest.mark.parametrize("flow", ["buckets", "records"])
 @pytest.mark.parametrize("k", [21, 51])
-def test_rccl_exchange_one_rank_matches_oracle(tmp_path, k):
+def test_rccl_exchange_one_rank_matches_oracle(tmp_path, k, flow):
     """the C++ exchange driven like count_kmers + KmerDHT, one-member communicator (the box has one GPU): blocks,
-    counts through RCCL, inserts ordered by events; result = the oracle's dump"""
+    sizes through RCCL, the receiving side ordered by events; result = the oracle's dump.  Both flows of the class: the
+    single-pass one (a shard owns level-1 buckets) and the records one (hash ownership)."""
     exe = build_exchange(tmp_path)
+    env = dict(os.environ, KC_EXCHANGE_FLOW=flow)
     rng = np.random.default_rng(78)
     reads, quals = random_reads(rng, 700, min_len=25, max_len=160, genome_len=2500, n_rate=0.0)
     masked = ["".join(c.lower() if ord(x) < 33 + 20 else c for c, x in zip(r, q)) for r, q in zip(reads, quals)]
-    out = subprocess.run([exe, str(k)], input="\n".join(masked) + "\n", capture_output=True, text=True, check=True).stdout
+    out = subprocess.run([exe, str(k)], input="\n".join(masked) + "\n", capture_output=True, text=True, check=True, env=env).stdout
     got = [l[5:] for l in out.splitlines() if l.startswith("KMER ")]
     (keys, counts, left, right), st = O.count_reads(reads, quals, k=k)
     want = sorted("%s %d %s %s" % (O.kmer_to_string(keys[i], k), counts[i], chr(left[i]), chr(right[i])) for i in range(len(counts)))

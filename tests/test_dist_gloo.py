@@ -53,7 +53,7 @@ def make_records(reads, quals, k, world):
     return bins
 
 
-def _worker(rank, world, port, k, tmp):
+def _worker(rank, world, port, k, tmp, flow="records"):
     os.environ["MASTER_ADDR"] = "127.0.0.1"
     os.environ["MASTER_PORT"] = str(port)
     dist.init_process_group("gloo", rank=rank, world_size=world)
@@ -89,7 +89,42 @@ def _worker(rank, world, port, k, tmp):
                 if re < 4:
                     e[2][re] = min(e[2][re] + 1, 65535)
 
-        sk = ShardedKmerAnalysis(extract, insert, nl, seg_capacity=20000, device="cpu")
+        # stand-ins of the single-pass flow (kc_shard_extract / kc_shard_reserve / kc_shard_commit): a wire segment is one
+        # header word (its records) + the records; the rank's own share never enters a segment; what arrives is used
+        # where reserve() put it
+        reserved = []
+
+        def shard_extract(block, send, seg_words):
+            bins = make_records([reads[i] for i in block], [quals[i] for i in block], k, world)
+            words = [0] * world
+            for d, recs in enumerate(bins):
+                if d == rank:
+                    if recs:
+                        insert(torch.from_numpy(np.concatenate(recs).astype(np.uint64).view(np.int64)), len(recs))
+                    continue
+                if not recs:
+                    continue  # nothing for this shard: no segment at all
+                flat = np.concatenate([np.array([len(recs)], dtype=np.uint64)] + recs).astype(np.uint64).view(np.int64)
+                assert len(flat) <= seg_words
+                send[d * seg_words:d * seg_words + len(flat)] = torch.from_numpy(flat)
+                words[d] = len(flat)
+            return words
+
+        def shard_reserve(nwords):
+            reserved.append(torch.full((nwords,), -1, dtype=torch.int64))
+            return reserved[-1]
+
+        def shard_commit(segment, nwords):
+            assert any(segment.data_ptr() >= r.data_ptr() and segment.data_ptr() + 8 * nwords <= r.data_ptr() + 8 * r.numel() for r in reserved)
+            assert segment.data_ptr() % 16 == 0
+            n = int(segment[0])
+            assert nwords == 1 + n * nl
+            insert(segment[1:], n)
+
+        if flow == "records":
+            sk = ShardedKmerAnalysis(extract, insert, nl, seg_capacity=20000, device="cpu")
+        else:
+            sk = ShardedKmerAnalysis(shard_extract, shard_commit, 1, seg_capacity=20000 * nl + 1, device="cpu", reserve=shard_reserve)
         for b0 in range(0, len(mine), 50):  # several blocks, the last one ragged
             sk.add_block(mine[b0:b0 + 50])
         sk.add_block([])  # a rank with nothing to send still takes part
@@ -100,6 +135,7 @@ def _worker(rank, world, port, k, tmp):
         for key in list(table)[::7]:
             kw = np.array(key, dtype=np.uint64)
             assert L.kc_owner(kw.ctypes.data, k, world) == rank
+        assert flow == "records" or all(int((r == -1).sum()) <= 1 for r in reserved)  # every reserved word arrived (one pad word at most)
         tot = torch.tensor([sk.sent, sk.received], dtype=torch.int64)
         dist.all_reduce(tot)
         assert int(tot[0]) == int(tot[1])  # nothing lost or duplicated in flight
@@ -117,11 +153,12 @@ def _worker(rank, world, port, k, tmp):
         dist.destroy_process_group()
 
 
+@pytest.mark.parametrize("flow", ["records", "single-pass"])
 @pytest.mark.parametrize("k", [21, 51])
-def test_two_rank_exchange_matches_single_rank_oracle(k, tmp_path):
+def test_two_rank_exchange_matches_single_rank_oracle(k, flow, tmp_path):
     world = 2
     port = _free_port()
-    mp.spawn(_worker, args=(world, port, k, str(tmp_path)), nprocs=world, join=True)
+    mp.spawn(_worker, args=(world, port, k, str(tmp_path), flow), nprocs=world, join=True)
     from helpers import random_reads, results_to_tuples
     from oracle import cpu_oracle as O
     rng = np.random.default_rng(77)

@@ -1,5 +1,5 @@
 """dist.py on the GPU: ShardedKmerAnalysis over the nccl backend (= RCCL) with the real device entry points
-(kc_extract_partition / kc_insert_records).  The box has one GPU, so the communicator has one member -- the N > 1
+(kc_extract_partition / kc_insert_records, and kc_shard_* for the single-pass flow).  The box has one GPU, so the communicator has one member -- the N > 1
 code path end to end (counts all-to-all, grouped send/recv, double buffering, the stream rule) minus the wire; two
 ranks over gloo are covered on the CPU by test_dist_gloo.py."""
 import os
@@ -25,8 +25,9 @@ def nccl_world1():
     dist.destroy_process_group()
 
 
+@pytest.mark.parametrize("flow", ["records", "single-pass"])
 @pytest.mark.parametrize("k,tuning", [(21, dict(p1=1024, p2=1024)), (51, None)], ids=["k21-compact", "k51"])
-def test_sharded_analysis_over_nccl(nccl_world1, k, tuning):
+def test_sharded_analysis_over_nccl(nccl_world1, k, tuning, flow):
     import torch
     from mhm2_kmer_analysis_v2_amd.dist import ShardedKmerAnalysis
     rng = np.random.default_rng(31 + k)
@@ -48,13 +49,22 @@ def test_sharded_analysis_over_nccl(nccl_world1, k, tuning):
             o0 = int(offs[r0])
             return kc.extract_partition(db[o0:], dq[o0:], do[r0:r1 + 1] - do[r0], send, seg_cap, nreads=r1 - r0)
 
-        sh = ShardedKmerAnalysis(extract, lambda recv, n: kc.insert_records(recv, n), nl, 600 * 150, dev, counter=kc)
+        def shard_extract(block, send, seg_words):
+            r0, r1 = block
+            o0 = int(offs[r0])
+            return kc.shard_extract(db[o0:], dq[o0:], do[r0:r1 + 1] - do[r0], send, seg_words, nreads=r1 - r0)
+
+        if flow == "records":
+            sh = ShardedKmerAnalysis(extract, lambda recv, n: kc.insert_records(recv, n), nl, 600 * 150, dev, counter=kc)
+        else:  # kc_shard_extract / kc_shard_reserve / kc_shard_commit: with one member nothing leaves the shard
+            sh = ShardedKmerAnalysis.single_pass(kc, shard_extract, 600 * 150 * nl + 2048, dev)
         for r0 in range(0, 4000, 600):  # seven blocks: both buffers are reused several times
             sh.add_block((r0, min(4000, r0 + 600)))
         sh.finish()
         got = kc.sorted_results()
         st = kc.stats()
-    assert sh.sent == sh.received == wst["kmers_inserted"]
+    assert sh.sent == sh.received == (wst["kmers_inserted"] if flow == "records" else 0)
+    assert st["kmers_inserted"] == wst["kmers_inserted"]
     for g, w in zip(got, want):
         assert g.shape == w.shape and (g == w).all()
     assert st["num_unique"] == wst["unique"]

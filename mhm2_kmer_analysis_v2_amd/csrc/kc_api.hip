@@ -637,6 +637,43 @@ static int bk_init(kc_ctx *c) {
   HIPCHK(hipMemsetAsync(b.cnt2, 0, (size_t)R * 4, c->stream));
   HIPCHK(hipMemsetAsync(b.flag, 0, (size_t)R * 4, c->stream));
   HIPCHK(hipMemsetAsync(c->d_cb, 0, CB_COUNT * 8, c->stream));
+  // The level-1 arena is written as G x P1 interleaved append streams, a pattern whose speed depends on how the driver
+  // happened to back the allocation: the same kernel on the same virtual addresses runs in 30 ms on one allocation and in
+  // 37-40 ms on another (measured, scripts/l1_mode_probe.py: fixed for the life of the allocation, mostly the first
+  // large allocations of a process).  One millisecond of that pattern alone tells them apart (0.83 vs 1.1-1.15 ms for
+  // 4.3 GB): a slow arena is given back and asked for again, a few times at most.  KC_ARENA_PROBE=0 switches this off.
+  {
+    const char *pe = getenv("KC_ARENA_PROBE");
+    const size_t wpw = (size_t)g.A1 * CH1 * c->nl;
+    if (!(pe && pe[0] == '0') && g.G >= (uint32_t)c->num_cus && wpw >= ((size_t)8 << 20)) {  // >= 64 MiB per writer: the benchmark's sizes
+      hipEvent_t e0, e1;
+      HIPCHK(hipEventCreate(&e0));
+      HIPCHK(hipEventCreate(&e1));
+      const uint32_t rounds = 256;
+      const double probe_bytes = (double)g.G * rounds * 65536.0;
+      for (int attempt = 0; attempt < 3; attempt++) {
+        float best = 1e30f;
+        for (int rep = 0; rep < 2; rep++) {
+          HIPCHK(hipEventRecord(e0, c->stream));
+          hipLaunchKernelGGL(kc_arena_probe_kernel, dim3(g.G), dim3(WGB), 0, c->stream, b.rec1, wpw, rounds);
+          HIPCHK(hipEventRecord(e1, c->stream));
+          HIPCHK(hipEventSynchronize(e1));
+          float ms = 0;
+          HIPCHK(hipEventElapsedTime(&ms, e0, e1));
+          best = std::min(best, ms);
+        }
+        const double tbps = probe_bytes / (best * 1e-3) / 1e12;
+        if (pe || getenv("KC_DEBUG_ADDR"))
+          fprintf(stderr, "kc arena probe: attempt %d, %.3f ms = %.2f TB/s, rec1 %p\n", attempt, best, tbps, (void *)b.rec1);
+        if (tbps >= 4.5 || attempt == 2) break;
+        HIPCHK(hipFree(b.rec1));
+        b.rec1 = nullptr;
+        HIPCHK(hipMalloc((void **)&b.rec1, rec1_bytes));
+      }
+      (void)hipEventDestroy(e0);
+      (void)hipEventDestroy(e1);
+    }
+  }
   if (getenv("KC_DEBUG_ADDR"))
     fprintf(stderr, "kc arenas: rec1 %p (%zu MB) chain1 %p cnt1 %p rec2 %p chain2 %p ovf1 %p ovf2 %p\n", (void *)b.rec1, rec1_bytes >> 20,
             (void *)b.chain1, (void *)b.cnt1, (void *)b.rec2, (void *)b.chain2, (void *)b.ovf1, (void *)b.ovf2);

@@ -392,6 +392,23 @@ __device__ __forceinline__ ChainState split_load_state(SplitLDS &L, uint32_t P, 
   return st;
 }
 
+// ---- how fast does this arena take level 1's write pattern? -------------------------------------------------------------
+// Every workgroup appends 64-byte runs round-robin to 1024 open chunks of its own part of the arena, the chunks taken
+// bump-style like a writer's: level 1's stores without the rest of level 1 (bk_init times it, see there).
+__global__ __launch_bounds__(WGB) void kc_arena_probe_kernel(uint64_t *arena, size_t words_per_wg, uint32_t rounds) {
+  uint64_t *mine = arena + (size_t)blockIdx.x * words_per_wg;
+  const uint32_t t = threadIdx.x, b = t >> 3, w = t & 7u;  // eight lanes write one 64-byte run
+  for (uint32_t r = 0; r < rounds; r++) {
+#pragma unroll
+    for (uint32_t j = 0; j < 8; j++) {
+      const uint32_t bucket = b + 128u * j;                                   // 1024 buckets per round
+      const size_t chunk = (size_t)bucket + 1024u * (size_t)(r >> 6);         // 512-record chunks: a new one every 64 rounds
+      const size_t at = chunk * 512u + (size_t)(r & 63u) * 8u + w;
+      if (at < words_per_wg) mine[at] = (uint64_t)r;
+    }
+  }
+}
+
 // ---- level 1 from reads ---------------------------------------------------------------------------
 struct L1LDS {
   TileLDS<TileSuper> tile;

@@ -193,8 +193,8 @@ __global__ __launch_bounds__(WGB) void kc_shard_index_kernel(const uint64_t *seg
       at[i] = (uint64_t)(uintptr_t)(recs + run * nl);
       run += s_n[i];
     }
+    // (CTR_EXPECT bounds what level 1 of THIS shard has buffered: received records never pass through it)
     atomicAdd((unsigned long long *)&ctrs[CTR_INSERTED], (unsigned long long)run);
-    atomicAdd((unsigned long long *)&ctrs[CTR_EXPECT], (unsigned long long)run);
   }
 }
 
@@ -212,7 +212,6 @@ __global__ __launch_bounds__(TPB) void kc_shard_loose_kernel(Geom gm, BucketBufs
   }
   if (blockIdx.x == 0 && threadIdx.x == 0) {
     atomicAdd((unsigned long long *)&ctrs[CTR_INSERTED], (unsigned long long)n);
-    atomicAdd((unsigned long long *)&ctrs[CTR_EXPECT], (unsigned long long)n);
   }
 }
 

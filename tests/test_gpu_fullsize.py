@@ -142,3 +142,63 @@ def test_heavy_hitters_match_the_oracle():
     for g, w in zip(got, want):
         assert g.shape == w.shape and (g == w).all()
     assert st["num_unique"] == ost["unique"] and st["num_dropped"] == 0
+
+
+@pytest.mark.parametrize("k,R", [(21, 2), (21, 4), (51, 2)])
+def test_single_pass_shard_flow_at_size(k, R):
+    """The single-pass shard flow (kc_shard_extract / kc_shard_reserve / kc_shard_commit) with R shards on one device,
+    KC_FULLSIZE_READS_LONG reads in all: the union of the shards is the result of one context over all the reads (same
+    checksum of checksums, distinct k-mers, sum of counts) -- and that context is what the tests above pin to the oracle."""
+    import torch
+    nreads = NREADS_LONG // R
+    p = pkg.synth_params()
+    est = int((64 * 4_000_000 + R * nreads * L * 0.005 * k * 1.05) / R) + (1 << 20)
+    bcap = int(nreads * (L - k - 1) * 1.05) + (1 << 20)
+    shards = [pkg.KmerCounter(k, rank_me=r, rank_n=R, max_elems=est, max_kmers_buffered=bcap, shard_buckets=True) for r in range(R)]
+    assert shards[0].shard_capacity() >= est
+    nl = shards[0].rec_nl
+    blocks = 3
+    blk = (nreads + blocks - 1) // blocks
+    seg_words = int(blk * (L - k - 1) / R * 1.1) * nl + 4096
+    segs = torch.zeros(R * seg_words, dtype=torch.int64, device="cuda")
+    data = []
+    for r in range(R):
+        db = torch.empty(nreads * L, dtype=torch.uint8, device="cuda")
+        dq = torch.empty(nreads * L, dtype=torch.uint8, device="cuda")
+        do = torch.empty(nreads + 1, dtype=torch.int64, device="cuda")
+        shards[r].synth_reads_device(db, dq, do, nreads, first_read=r * nreads, params=p)
+        data.append((db, dq, do))
+    for r0 in range(0, nreads, blk):
+        r1 = min(nreads, r0 + blk)
+        for r in range(R):
+            db, dq, do = data[r]
+            words = shards[r].shard_extract(db[r0 * L:], dq[r0 * L:], do[r0:r1 + 1] - do[r0], segs, seg_words, nreads=r1 - r0)
+            for d in range(R):
+                w = int(words[d])
+                if d == r or not w:
+                    continue
+                dst = shards[d].shard_reserve(w)
+                dst.copy_(segs[d * seg_words:d * seg_words + w])
+                torch.cuda.synchronize()
+                shards[d].shard_commit(dst, w)
+    x, s, n, uniq, sumc, ins = 0, 0, 0, 0, 0, 0
+    for sh in shards:
+        c = checksum(sh)
+        st = sh.stats()
+        assert st["num_dropped"] == 0 and c[2] > 0
+        x ^= c[0]
+        s = (s + c[1]) & (2 ** 64 - 1)
+        n += c[2]
+        uniq += st["num_unique"]
+        sumc += st["sum_counts"]
+        ins += st["kmers_inserted"]
+        sh.close()
+    del segs
+    assert ins == R * nreads * (L - k - 1)
+    with pkg.KmerCounter(k, max_elems=est * R, max_kmers_buffered=bcap * R) as one:
+        for db, dq, do in data:
+            one.submit_reads(db, dq, do, nreads=nreads)
+        c = checksum(one)
+        st = one.stats()
+    assert (x, s, n) == c
+    assert (uniq, sumc) == (st["num_unique"], st["sum_counts"])

@@ -1070,27 +1070,32 @@ constexpr uint32_t CHAIN_LDS = 512;  // longest region chain (L2MAX) the count k
 
 // LDS image of one region, structure-of-arrays so that neighbouring slots sit in neighbouring banks.
 // The table size is a power of two (cheap wrap, low load: a lane's probe sequence is as long as the run of occupied
-// slots it starts in).  Ten 16-bit counters per entry in five words: the four extensions of either side and, per side,
+// slots it starts in).  Ten 16-bit counters per entry: the four extensions of either side and, per side,
 // the occurrences that came WITHOUT a usable extension -- so that the k-mer's own count is the sum of one side's five
 // and need not be counted separately (two LDS adds per occurrence instead of three).  No half can overflow in a region
 // of at most 65535 records; a larger one (a k-mer seen more often than that, S6) is handed whole to the global table
 // (flag 2), whose counters are 32 bits wide.
+// One-word k-mers spend a sixth word on them so that each side has three words of its own: the word and the half an
+// extension code e (0-3 = ACGT, 4 = none) bumps are then e >> 1 and e & 1, no selects (the instruction count of an
+// occurrence is what bounds the kernel).  Longer keys keep the five-word layout, which is what fits beside them.
 template <int NL>
 struct CountLDS {  // header at the start of the dynamic LDS; the arrays follow, strided by the region's S
   static constexpr uint32_t SMAX = NL <= 2 ? 4096 : 2048;
+  static constexpr int EW = NL == 1 ? 6 : 5;  // extension words per slot; the last one takes the vote's result
   uint32_t chain[CHAIN_LDS];  // the region's chunk ids
   uint32_t nout, nocc, fail, gbase_lo, gbase_hi;
   uint32_t gbase2_lo, gbase2_hi, split;  // ranks >= split continue at gbase2 (a region may straddle two blocks)
   unsigned long long sum;
   static constexpr size_t header_bytes() { return (sizeof(CountLDS<NL>) + 15) & ~size_t(15); }
   // cp: compact records, 32-bit keys
-  static constexpr size_t bytes(uint32_t S, bool cp) { return header_bytes() + (size_t)S * ((cp ? 4 : 8 * NL) + 20 + 2) + 16; }
+  static constexpr size_t bytes(uint32_t S, bool cp) { return header_bytes() + (size_t)S * ((cp ? 4 : 8 * NL) + 4 * EW + 2) + 16; }
 };
 
 // the arrays of one region table: word w of slot s at keys[w*S + s] (the LAST word is the claim word; compact
 // records: one 32-bit key per slot);
-// ext[q*S + s]: q = 0 left A|C<<16, 1 left G|T<<16, 2 right A|C<<16, 3 right G|T<<16, 4 left none | right none<<16
-// (after the vote an entry's word 4 holds its count, extensions and rank for the write-out)
+// ext[q*S + s], five words (EW = 5): q = 0 left A|C<<16, 1 left G|T<<16, 2 right A|C<<16, 3 right G|T<<16,
+// 4 left none | right none<<16; six words: q = 0 left A|C<<16, 1 left G|T<<16, 2 left none, 3-5 the same of the right
+// (after the vote an entry's last word holds its count, extensions and rank for the write-out)
 // occ lists the occupied slots in claim order, so that the vote, the write-out and the clean-up of a region visit
 // only its entries (dense lanes) instead of scanning every slot
 struct CountTab {
@@ -1107,22 +1112,31 @@ __device__ __forceinline__ CountTab count_tab(uint8_t *smem, uint32_t S) {
   t.keys = reinterpret_cast<uint64_t *>(p);
   p += (size_t)S * (CP ? 4 : 8 * NL);
   t.ext = reinterpret_cast<uint32_t *>(p);
-  t.occ = reinterpret_cast<uint16_t *>(t.ext + 5 * (size_t)S);
+  t.occ = reinterpret_cast<uint16_t *>(t.ext + CountLDS<NL>::EW * (size_t)S);
   t.S = S;
   t.lgS = 31u - (uint32_t)__clz(S);
   return t;
 }
 
 // one occurrence with extension codes le, re (0-3 = ACGT, >= 4 = none) at slot s: S5/S6 in two LDS adds
+template <int EW>
 __device__ __forceinline__ void ext_count(const CountTab &tb, uint32_t s, uint32_t le, uint32_t re) {
-  const bool nl = (le & 4u) != 0, nr = (re & 4u) != 0;
-  const uint32_t wl = nl ? 4u : (le >> 1), wr = nr ? 4u : 2u + (re >> 1);
-  const uint32_t il = nl ? 1u : 1u << ((le & 1u) << 4), ir = nr ? 0x10000u : 1u << ((re & 1u) << 4);
-  atomicAdd(&tb.ext[(wl << tb.lgS) + s], il);
-  atomicAdd(&tb.ext[(wr << tb.lgS) + s], ir);
+  if constexpr (EW == 6) {
+    le = min(le, 4u);  // any code >= 4 means "none"
+    re = min(re, 4u);
+    atomicAdd(&tb.ext[((le >> 1) << tb.lgS) + s], 1u << ((le & 1u) << 4));
+    atomicAdd(&tb.ext[((3u + (re >> 1)) << tb.lgS) + s], 1u << ((re & 1u) << 4));
+  } else {
+    const bool nl = (le & 4u) != 0, nr = (re & 4u) != 0;
+    const uint32_t wl = nl ? 4u : (le >> 1), wr = nr ? 4u : 2u + (re >> 1);
+    const uint32_t il = nl ? 1u : 1u << ((le & 1u) << 4), ir = nr ? 0x10000u : 1u << ((re & 1u) << 4);
+    atomicAdd(&tb.ext[(wl << tb.lgS) + s], il);
+    atomicAdd(&tb.ext[(wr << tb.lgS) + s], ir);
+  }
 }
+template <int EW>
 __device__ __forceinline__ uint32_t ext_get(const uint32_t *ext, uint32_t SM, uint32_t s, uint32_t side, uint32_t e) {
-  return (ext[(2 * side + (e >> 1)) * SM + s] >> (16 * (e & 1u))) & 0xFFFFu;
+  return (ext[((EW == 6 ? 3 : 2) * side + (e >> 1)) * SM + s] >> (16 * (e & 1u))) & 0xFFFFu;
 }
 
 struct OutBufs {
@@ -1186,8 +1200,12 @@ __device__ __forceinline__ uint32_t lds_probe1(unsigned long long *claim, uint32
 // of a 64-bit one.  EMPTY is all ones, which no key is (a key has at most 26 bits).  (Reading the slot first and
 // claiming only an empty one -- reads of one address share an access, compare-and-swaps of one address queue -- was
 // measured 6 % slower: the extra dependent LDS trip of the new keys costs more than the queueing.)
-__device__ __forceinline__ uint32_t lds_probe32(uint32_t *claim, uint32_t Sm1, uint32_t key, uint32_t slot, uint32_t valid, uint32_t &failed) {
-  uint32_t act = valid, trips = 0;
+// The probe sequence steps by an odd stride taken from the key's bits above the start slot (every slot is visited once
+// in S steps, and keys that collide on a slot part ways at once): the lanes of a wave probe in lock step, a wave pays
+// for its longest probe, and without the clusters of a unit stride the longest of 64 is shorter.
+__device__ __forceinline__ uint32_t lds_probe32(uint32_t *claim, uint32_t Sm1, uint32_t key, uint32_t slot, uint32_t stride, uint32_t valid,
+                                                uint32_t &failed) {
+  uint32_t act = valid ? stride : 0u, trips = 0;  // a live lane's step, 0 for a lane that is done
   do {
     uint32_t old = key;  // a lane that is done looks like a hit below
     if (act) old = atomicCAS(&claim[slot], 0xFFFFFFFFu, key);
@@ -1249,6 +1267,7 @@ __global__ __launch_bounds__(WGB, 8) void kc_count_kernel(Geom gm, BucketBufs bb
   CountLDS<NL> &T = *reinterpret_cast<CountLDS<NL> *>(smem);
   const int tid = threadIdx.x;
   const uint32_t S = gm.S, SM = gm.S;
+  constexpr int EW = CountLDS<NL>::EW;
   const CountTab tb = count_tab<NL, CP>(smem, S);
   const size_t R = (size_t)gm.P1 * gm.P2;
   // diagnostic builds only (-DKC_STAMPS): thread 0 accumulates the cycles between the phase boundaries of every region
@@ -1275,7 +1294,7 @@ __global__ __launch_bounds__(WGB, 8) void kc_count_kernel(Geom gm, BucketBufs bb
       for (int w = 0; w < NL; w++) tb.keys[w * SM + s] = KEY_EMPTY;
     }
 #pragma unroll
-    for (int e = 0; e < 5; e++) tb.ext[e * SM + s] = 0;
+    for (int e = 0; e < EW; e++) tb.ext[e * SM + s] = 0;
   };
   for (uint32_t s = tid; s < S; s += WGB) reset_slot(s);
   if (tid == 0) T.nocc = 0;
@@ -1337,11 +1356,11 @@ __global__ __launch_bounds__(WGB, 8) void kc_count_kernel(Geom gm, BucketBufs bb
           const uint32_t v = (i0 + (uint32_t)j * WGB + tid) < n ? 1u : 0u;
           const uint32_t r0 = rec32[j], key = r0 >> 6;
           if (!__any(v)) continue;  // past the end of the region for the whole wave
-          const uint32_t s = lds_probe32(keys32, S - 1u, key, key & (S - 1u), v, failed);
+          const uint32_t s = lds_probe32(keys32, S - 1u, key, key & (S - 1u), ((key >> tb.lgS) << 1) | 1u, v, failed);
           const uint32_t le = r0 & 7u, re = (r0 >> 3) & 7u;
           // only lanes that hold a record touch the counters: the idle lanes of a wave all re-read record 0, and 64
           // atomic adds of zero to one LDS word are serialised
-          if (v) ext_count(tb, s, le, re);
+          if (v) ext_count<EW>(tb, s, le, re);
         }
         if (failed) T.fail = 1;
       } else if constexpr (NL == 1) {
@@ -1356,7 +1375,7 @@ __global__ __launch_bounds__(WGB, 8) void kc_count_kernel(Geom gm, BucketBufs bb
           // S5/S6: the k-mer itself, and each extension that is an ACGT base (codes 0-3; 4 = none adds 0).  Only
           // lanes that hold a record touch the counters (see the compact path above)
           const uint32_t le = (uint32_t)r0 & 7u, re = ((uint32_t)r0 >> 3) & 7u;
-          if (v) ext_count(tb, s, le, re);
+          if (v) ext_count<EW>(tb, s, le, re);
         }
         if (failed) T.fail = 1;
       } else {
@@ -1371,7 +1390,7 @@ __global__ __launch_bounds__(WGB, 8) void kc_count_kernel(Geom gm, BucketBufs bb
           const uint32_t le = (uint32_t)(rec[j][NL - 1] & 7u), re = (uint32_t)((rec[j][NL - 1] >> 3) & 7u);
           key[NL - 1] &= ~KC_EXT_MASK;
           const uint32_t s = lds_probeN<NL>(tb, key, hash_slot(kc_hash<NL>(key), S), v, failed);
-          if (v && !(failed & 1u)) ext_count(tb, s, le, re);
+          if (v && !(failed & 1u)) ext_count<EW>(tb, s, le, re);
         }
         if (failed) T.fail = 1;
       }
@@ -1397,20 +1416,19 @@ __global__ __launch_bounds__(WGB, 8) void kc_count_kernel(Geom gm, BucketBufs bb
       const uint32_t e = e0 + tid;
       const bool live = e < nocc;
       const uint32_t s = live ? tb.occ[e] : 0u;
-      uint32_t w[5] = {0, 0, 0, 0, 0};
-      if (live) {
+      uint32_t w[EW];
 #pragma unroll
-        for (int x = 0; x < 5; x++) w[x] = tb.ext[x * SM + s];
-      }
+      for (int x = 0; x < EW; x++) w[x] = live ? tb.ext[x * SM + s] : 0u;
       // the k-mer's count: every occurrence bumped exactly one of the left side's five counters (<= 65535: n is)
-      const uint32_t count = (w[0] & 0xFFFFu) + (w[0] >> 16) + (w[1] & 0xFFFFu) + (w[1] >> 16) + (w[4] & 0xFFFFu);
+      const uint32_t count = (w[0] & 0xFFFFu) + (w[0] >> 16) + (w[1] & 0xFFFFu) + (w[1] >> 16) + (w[EW == 6 ? 2 : 4] & 0xFFFFu);
       bool keep = false;
       uint32_t l = 0, rr = 0;
       if (DUMP) {
         keep = live;
       } else if (count >= 2) {
         const uint32_t lc[4] = {w[0] & 0xFFFFu, w[0] >> 16, w[1] & 0xFFFFu, w[1] >> 16};
-        const uint32_t rc[4] = {w[2] & 0xFFFFu, w[2] >> 16, w[3] & 0xFFFFu, w[3] >> 16};
+        constexpr int R0 = EW == 6 ? 3 : 2;
+        const uint32_t rc[4] = {w[R0] & 0xFFFFu, w[R0] >> 16, w[R0 + 1] & 0xFFFFu, w[R0 + 1] >> 16};
         l = vote_ext(lc, count, dmin_thres);
         rr = vote_ext(rc, count, dmin_thres);
         keep = l < 4u && rr < 4u;
@@ -1426,10 +1444,10 @@ __global__ __launch_bounds__(WGB, 8) void kc_count_kernel(Geom gm, BucketBufs bb
         if (lane_id() == 0 && !DUMP) atomicAdd(&T.sum, (unsigned long long)wsum);
         if (keep) {
           const uint32_t rank = base + (uint32_t)__popcll(m & ((1ULL << lane_id()) - 1ULL));
-          tb.ext[4 * SM + s] = DUMP ? (count | (rank << 20)) : ((count & 0xFFFFu) | (l << 16) | (rr << 18) | (rank << 20));
+          tb.ext[(EW - 1) * SM + s] = DUMP ? (count | (rank << 20)) : ((count & 0xFFFFu) | (l << 16) | (rr << 18) | (rank << 20));
         }
       }
-      if (live && !keep) tb.ext[4 * SM + s] = ~0u;
+      if (live && !keep) tb.ext[(EW - 1) * SM + s] = ~0u;
     }
     __syncthreads();
     if (T.fail) {  // more distinct k-mers than slots, or a saturated k-mer: the whole region goes to the global table instead
@@ -1478,7 +1496,7 @@ __global__ __launch_bounds__(WGB, 8) void kc_count_kernel(Geom gm, BucketBufs bb
     const uint32_t split = T.split;
     for (uint32_t e = tid; e < nocc; e += WGB) {
       const uint32_t s = tb.occ[e];
-      const uint32_t p = tb.ext[4 * SM + s];
+      const uint32_t p = tb.ext[(EW - 1) * SM + s];
       if (p != ~0u) {
         const uint32_t rank = p >> 20;
         const uint64_t o = rank < split ? gbase + rank : gbase2 + (rank - split);
@@ -1492,7 +1510,7 @@ __global__ __launch_bounds__(WGB, 8) void kc_count_kernel(Geom gm, BucketBufs bb
           out.counts[o] = (uint16_t)(p & 0xFFFFu);
           if (DUMP) {
 #pragma unroll
-            for (int x = 0; x < 8; x++) out.exts[o * 8 + x] = (uint16_t)ext_get(tb.ext, SM, s, x >> 2, x & 3);
+            for (int x = 0; x < 8; x++) out.exts[o * 8 + x] = (uint16_t)ext_get<EW>(tb.ext, SM, s, x >> 2, x & 3);
           } else {
             out.left[o] = (uint8_t)("ACGT"[(p >> 16) & 3u]);
             out.right[o] = (uint8_t)("ACGT"[(p >> 18) & 3u]);

@@ -542,6 +542,59 @@ static uint32_t ilog2(uint64_t v) {
   return l;
 }
 
+// The same split kernel on the same virtual addresses runs at different speeds on different ALLOCATIONS of its arena:
+// level 1 in 30-32 ms on one, in 36 ms or in 40 ms on another, level 2 in 26.8 or 27.8 ms (measured,
+// scripts/l1_mode_probe.py and scripts/probe_runs.sh: fixed for the life of the allocation; how the driver backed the
+// memory is the suspect).  One millisecond of the kernels' write pattern alone -- every workgroup appending 64-byte runs
+// round-robin to 1024 open chunks of its own part (kc_arena_probe_kernel) -- tells the allocations apart: 4.3 GB at
+// >= 4.9 TB/s on a fast arena, 3.6-4.3 TB/s on a slow one.  Freeing a slow arena and asking again tends to return the
+// same memory, so a slow one is HELD while another is asked for (when the device has the room), at most four in all;
+// the fastest is kept.  KC_ARENA_PROBE=0 switches this off, =1 logs.
+static int pick_fast_arena(kc_ctx *c, uint64_t **arena, size_t bytes, uint32_t G, const char *what) {
+  const char *pe = getenv("KC_ARENA_PROBE");
+  hipEvent_t e0, e1;
+  HIPCHK(hipEventCreate(&e0));
+  HIPCHK(hipEventCreate(&e1));
+  const uint32_t rounds = 256;
+  const size_t wpw = bytes / 8 / G;
+  const double probe_bytes = (double)G * rounds * 65536.0;
+  constexpr int NCAND = 4;
+  uint64_t *cand[NCAND] = {*arena, nullptr, nullptr, nullptr};
+  double rate[NCAND] = {0, 0, 0, 0};
+  int ncand = 1, best_i = 0;
+  for (int i = 0; i < NCAND; i++) {
+    float best = 1e30f;
+    for (int rep = 0; rep < 2; rep++) {
+      HIPCHK(hipEventRecord(e0, c->stream));
+      hipLaunchKernelGGL(kc_arena_probe_kernel, dim3(G), dim3(WGB), 0, c->stream, cand[i], wpw, rounds);
+      HIPCHK(hipEventRecord(e1, c->stream));
+      HIPCHK(hipEventSynchronize(e1));
+      float ms = 0;
+      HIPCHK(hipEventElapsedTime(&ms, e0, e1));
+      best = std::min(best, ms);
+    }
+    rate[i] = probe_bytes / (best * 1e-3) / 1e12;
+    if (rate[i] > rate[best_i]) best_i = i;
+    if (pe || getenv("KC_DEBUG_ADDR"))
+      fprintf(stderr, "kc arena probe (%s): allocation %d, %.3f ms = %.2f TB/s, %p\n", what, i, best, rate[i], (void *)cand[i]);
+    if (rate[i] >= 4.8 || i == NCAND - 1) break;
+    size_t free_b = 0, total_b = 0;
+    if (hipMemGetInfo(&free_b, &total_b) != hipSuccess || free_b < bytes + ((size_t)8 << 30)) break;  // no room to hold another
+    if (hipMalloc((void **)&cand[i + 1], bytes) != hipSuccess) {
+      (void)hipGetLastError();
+      cand[i + 1] = nullptr;
+      break;
+    }
+    ncand = i + 2;
+  }
+  for (int i = 0; i < ncand; i++)
+    if (i != best_i && cand[i]) HIPCHK(hipFree(cand[i]));
+  *arena = cand[best_i];
+  (void)hipEventDestroy(e0);
+  (void)hipEventDestroy(e1);
+  return KC_OK;
+}
+
 // Choose the geometry from the configured sizes and allocate the level-1 / level-2 arenas.
 static int bk_init(kc_ctx *c) {
   if (c->bk_ready) return KC_OK;
@@ -637,55 +690,15 @@ static int bk_init(kc_ctx *c) {
   HIPCHK(hipMemsetAsync(b.cnt2, 0, (size_t)R * 4, c->stream));
   HIPCHK(hipMemsetAsync(b.flag, 0, (size_t)R * 4, c->stream));
   HIPCHK(hipMemsetAsync(c->d_cb, 0, CB_COUNT * 8, c->stream));
-  // The level-1 arena is written as G x P1 interleaved append streams, a pattern whose speed depends on how the driver
-  // happened to back the allocation: the same kernel on the same virtual addresses runs in 30-32 ms on one allocation,
-  // in 36 ms or in 40 ms on another (measured, scripts/l1_mode_probe.py and scripts/probe_runs.sh: fixed for the life of
-  // the allocation).  One millisecond of that pattern alone tells them apart (4.3 GB at >= 4.9 TB/s on a fast arena,
-  // 4.3 on a 36 ms one, 3.6-3.9 on a 40 ms one).  Freeing a slow arena and asking again tends to return the same
-  // memory, so a slow one is HELD while another is asked for (when the device has the room), at most three in all;
-  // the fastest is kept.  KC_ARENA_PROBE=0 switches this off, =1 logs.
+  // The arenas are written as many interleaved append streams (level 1: G x P1, level 2: P2 per bucket workgroup), a
+  // pattern whose speed depends on how the driver happened to back the allocation: pick_fast_arena
   {
     const char *pe = getenv("KC_ARENA_PROBE");
-    const size_t wpw = (size_t)g.A1 * CH1 * c->nl;
-    if (!(pe && pe[0] == '0') && g.G >= (uint32_t)c->num_cus && wpw >= ((size_t)8 << 20)) {  // >= 64 MiB per writer: the benchmark's sizes
-      hipEvent_t e0, e1;
-      HIPCHK(hipEventCreate(&e0));
-      HIPCHK(hipEventCreate(&e1));
-      const uint32_t rounds = 256;
-      const double probe_bytes = (double)g.G * rounds * 65536.0;
-      uint64_t *cand[3] = {b.rec1, nullptr, nullptr};
-      double rate[3] = {0, 0, 0};
-      int ncand = 1, best_i = 0;
-      for (int i = 0; i < 3; i++) {
-        float best = 1e30f;
-        for (int rep = 0; rep < 2; rep++) {
-          HIPCHK(hipEventRecord(e0, c->stream));
-          hipLaunchKernelGGL(kc_arena_probe_kernel, dim3(g.G), dim3(WGB), 0, c->stream, cand[i], wpw, rounds);
-          HIPCHK(hipEventRecord(e1, c->stream));
-          HIPCHK(hipEventSynchronize(e1));
-          float ms = 0;
-          HIPCHK(hipEventElapsedTime(&ms, e0, e1));
-          best = std::min(best, ms);
-        }
-        rate[i] = probe_bytes / (best * 1e-3) / 1e12;
-        if (rate[i] > rate[best_i]) best_i = i;
-        if (pe || getenv("KC_DEBUG_ADDR"))
-          fprintf(stderr, "kc arena probe: allocation %d, %.3f ms = %.2f TB/s, rec1 %p\n", i, best, rate[i], (void *)cand[i]);
-        if (rate[i] >= 4.8 || i == 2) break;
-        size_t free_b = 0, total_b = 0;
-        if (hipMemGetInfo(&free_b, &total_b) != hipSuccess || free_b < rec1_bytes + ((size_t)8 << 30)) break;  // no room to hold two
-        if (hipMalloc((void **)&cand[i + 1], rec1_bytes) != hipSuccess) {
-          (void)hipGetLastError();
-          cand[i + 1] = nullptr;
-          break;
-        }
-        ncand = i + 2;
-      }
-      for (int i = 0; i < ncand; i++)
-        if (i != best_i && cand[i]) HIPCHK(hipFree(cand[i]));
-      b.rec1 = cand[best_i];
-      (void)hipEventDestroy(e0);
-      (void)hipEventDestroy(e1);
+    if (!(pe && pe[0] == '0') && g.G >= (uint32_t)c->num_cus && (size_t)g.A1 * CH1 * c->nl >= ((size_t)8 << 20)) {  // the benchmark's sizes
+      int rc = pick_fast_arena(c, &b.rec1, rec1_bytes, g.G, "level 1");
+      if (rc) return rc;
+      rc = pick_fast_arena(c, reinterpret_cast<uint64_t **>(&b.rec2), rec2_bytes, g.G, "level 2");
+      if (rc) return rc;
     }
   }
   if (getenv("KC_DEBUG_ADDR"))

@@ -1205,19 +1205,23 @@ __device__ __forceinline__ uint32_t lds_probe1(unsigned long long *claim, uint32
 // for its longest probe, and without the clusters of a unit stride the longest of 64 is shorter.
 __device__ __forceinline__ uint32_t lds_probe32(uint32_t *claim, uint32_t Sm1, uint32_t key, uint32_t slot, uint32_t stride, uint32_t valid,
                                                 uint32_t &failed) {
-  uint32_t act = valid ? stride : 0u, trips = 0;  // a live lane's step, 0 for a lane that is done
+  // slot and step as byte offsets (the LDS address is then the slot itself plus an immediate); a live lane's step,
+  // 0 for a lane that is done.  The kernel is bound by its vector instruction count: the two compares of a trip
+  // leave their results in scalar registers and are combined there.
+  uint32_t trips = 0, at = slot << 2;
+  const uint32_t m4 = Sm1 << 2, step = stride << 2;
+  bool go = valid != 0;  // this lane is still probing (a lane mask in scalar registers)
   do {
     uint32_t old = key;  // a lane that is done looks like a hit below
-    if (act) old = atomicCAS(&claim[slot], 0xFFFFFFFFu, key);
-    const uint32_t miss = min(old ^ key, ~old) ? act : 0u;  // neither this key nor (until now) empty
-    act = miss;
-    slot = (slot + miss) & Sm1;
+    if (go) old = atomicCAS(reinterpret_cast<uint32_t *>(reinterpret_cast<char *>(claim) + at), 0xFFFFFFFFu, key);
+    go = go & (old != key) & (old != 0xFFFFFFFFu);  // neither this key nor (until now) empty
+    at = (at + (go ? step : 0u)) & m4;
     if (++trips > Sm1 + 1) {  // every slot holds some other k-mer (wave-uniform exit)
-      failed |= act;
+      failed |= go ? 1u : 0u;
       break;
     }
-  } while (__any(act));
-  return slot;
+  } while (__builtin_amdgcn_ballot_w64(go) != 0);
+  return at >> 2;
 }
 
 // Several-word keys, same style: the last word is the claim word (EMPTY -> BUSY -> the key's last word), the others

@@ -139,3 +139,62 @@ def test_shard_flow_errors():
     assert e.value.status == -1
     a.close()
     c.close()
+
+
+def test_shard_flow_again_after_reset():
+    """kc_reset starts a new pass: the received segments are forgotten, their memory is reused, the result is the same."""
+    import torch
+    k, R = 21, 2
+    rng = np.random.default_rng(17)
+    reads, quals = random_reads(rng, 800, min_len=30, max_len=150, genome_len=2500)
+    b, q, offs = arrays(reads, quals)
+    want, _, _ = oracle_run(b, q, offs, k)
+    shards = [pkg.KmerCounter(k, rank_me=r, rank_n=R, tuning=PATHS["compact"]) for r in range(R)]
+    total = sum(max(0, len(r) - k - 1) for r in reads)
+    seg_words = total + 2048
+    segs = torch.zeros(R * seg_words, dtype=torch.int64, device="cuda")
+    first_ptrs = None
+    for rep in range(3):
+        ptrs = []
+        for r in range(R):
+            part = list(range(r, len(reads), R))
+            bb, qq, oo = arrays([reads[i] for i in part], [quals[i] for i in part])
+            words = shards[r].shard_extract(bb, qq, oo, segs, seg_words)
+            d = 1 - r
+            w = int(words[d])
+            dst = shards[d].shard_reserve(w)
+            ptrs.append(dst.data_ptr())
+            dst.copy_(segs[d * seg_words:d * seg_words + w])
+            torch.cuda.synchronize()
+            shards[d].shard_commit(dst, w)
+        assert_same(union([s.sorted_results() for s in shards]), want)
+        if first_ptrs is None:
+            first_ptrs = ptrs
+        assert ptrs == first_ptrs  # the extents of the first pass are reused
+        for s in shards:
+            s.reset()
+    for s in shards:
+        s.close()
+
+
+def test_too_many_segments_in_one_pass_is_reported():
+    import torch
+    k = 21
+    tuning = dict(writers=300, p1=256, p2=256, slots=512)  # 512 - 300 writers leave room for 212 flat sources
+    a = pkg.KmerCounter(k, rank_me=0, rank_n=2, tuning=tuning)
+    c = pkg.KmerCounter(k, rank_me=1, rank_n=2, tuning=tuning)
+    reads, quals = ["ACGTTGCATGCCGTAAGCTTAGCGATCGATTGCA" * 2], ["I" * 68]
+    b, q, offs = arrays(reads, quals)
+    segs = torch.zeros(2 * 4096, dtype=torch.int64, device="cuda")
+    with pytest.raises(pkg.KcError) as e:
+        for i in range(300):
+            words = a.shard_extract(b, q, offs, segs, 4096)
+            w = int(words[1])
+            assert w > 0
+            dst = c.shard_reserve(w)
+            dst.copy_(segs[4096:4096 + w])
+            torch.cuda.synchronize()
+            c.shard_commit(dst, w)
+    assert e.value.status == -6 and i == 212
+    a.close()
+    c.close()

@@ -203,8 +203,8 @@ def test_too_many_segments_in_one_pass_is_reported():
 def test_shard_capacity_follows_the_geometry():
     """kc_shard_capacity: a shard's share of the regions; KC_FLAG_SHARD_BUCKETS sizes the geometry for the flow."""
     k, est = 21, 40_000_000
-    with pkg.KmerCounter(k, rank_me=0, rank_n=1, max_elems=est) as one, \\
-            pkg.KmerCounter(k, rank_me=1, rank_n=4, max_elems=est) as plain, \\
+    with pkg.KmerCounter(k, rank_me=0, rank_n=1, max_elems=est) as one, \
+            pkg.KmerCounter(k, rank_me=1, rank_n=4, max_elems=est) as plain, \
             pkg.KmerCounter(k, rank_me=1, rank_n=4, max_elems=est, shard_buckets=True) as flow:
         c1, cp, cf = one.shard_capacity(), plain.shard_capacity(), flow.shard_capacity()
     assert c1 >= est                 # a single shard owns every region of a geometry made for est

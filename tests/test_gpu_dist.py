@@ -68,3 +68,90 @@ def test_sharded_analysis_over_nccl(nccl_world1, k, tuning, flow):
     for g, w in zip(got, want):
         assert g.shape == w.shape and (g == w).all()
     assert st["num_unique"] == wst["unique"]
+
+
+def _two_process_worker(rank, world, port, k, tmp):
+    """One process per shard, both on the one GPU of the box; the wire is gloo over CPU staging (RCCL refuses two ranks
+    on one device), everything else is the real thing: kc_shard_extract / kc_shard_reserve / kc_shard_commit through
+    dist.py's single-pass protocol."""
+    import torch
+    import torch.distributed as dist
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        from mhm2_kmer_analysis_v2_amd.dist import ShardedKmerAnalysis
+        rng = np.random.default_rng(91)  # the same reads in every process; each takes its own slice
+        reads, quals = random_reads(rng, 3000, min_len=k - 2, max_len=k + 120, genome_len=5000)
+        mine = list(range(rank, len(reads), world))
+        kc = pkg.KmerCounter(k, rank_me=rank, rank_n=world, tuning=dict(writers=5, p1=256, p2=256, slots=512) if k == 21 else None,
+                             shard_buckets=True)
+        nl = kc.rec_nl
+        seg_words = 400 * 150 * nl + 2048
+        segs = torch.zeros(world * seg_words, dtype=torch.int64, device="cuda")
+
+        def extract(block, send, seg):
+            b, q, offs = O.reads_to_arrays([reads[i] for i in block], [quals[i] for i in block])
+            words = kc.shard_extract(b, q, offs, segs, seg)
+            for d in range(world):
+                w = int(words[d])
+                if w:
+                    send[d * seg:d * seg + w] = segs[d * seg:d * seg + w].cpu()
+            return words
+
+        staged = []
+
+        def reserve(nwords):
+            staged.append(torch.empty(nwords, dtype=torch.int64))
+            return staged[-1]
+
+        def commit(segment, nwords):
+            dst = kc.shard_reserve(nwords)
+            dst.copy_(segment)
+            torch.cuda.synchronize()
+            kc.shard_commit(dst, nwords)
+
+        sk = ShardedKmerAnalysis(extract, commit, 1, seg_words, "cpu", reserve=reserve)
+        for b0 in range(0, len(mine), 400):
+            sk.add_block(mine[b0:b0 + 400])
+        sk.add_block([])
+        sk.finish()
+        keys, counts, left, right = kc.sorted_results()
+        st = kc.stats()
+        for i in range(0, len(counts), 41):
+            assert kc.shard_owner(keys[i]) == rank
+        tot = torch.tensor([sk.sent, sk.received, st["kmers_inserted"]], dtype=torch.int64)
+        dist.all_reduce(tot)
+        assert int(tot[0]) == int(tot[1]) and int(tot[0]) > 0
+        np.savez(os.path.join(tmp, "shard%d.npz" % rank), keys=keys, counts=counts, left=left, right=right, inserted=int(tot[2]))
+        kc.close()
+    finally:
+        dist.destroy_process_group()
+
+
+@pytest.mark.parametrize("k", [21, 51])
+def test_two_processes_single_pass_flow(k, tmp_path):
+    import socket
+    import torch.multiprocessing as mp
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    port = s.getsockname()[1]
+    s.close()
+    world = 2
+    mp.spawn(_two_process_worker, args=(world, port, k, str(tmp_path)), nprocs=world, join=True)
+    rng = np.random.default_rng(91)
+    reads, quals = random_reads(rng, 3000, min_len=k - 2, max_len=k + 120, genome_len=5000)
+    b, q, offs = O.reads_to_arrays(reads, quals)
+    o = O.Oracle(k, nranks=3, nthreads=2)
+    o.add_reads(b, q, offs)
+    want = o.finalize()
+    wst = o.stats()
+    o.close()
+    parts = [np.load(os.path.join(str(tmp_path), "shard%d.npz" % r)) for r in range(world)]
+    assert int(parts[0]["inserted"]) == wst["kmers_inserted"]
+    keys = np.concatenate([p["keys"] for p in parts])
+    order = np.lexsort([keys[:, j] for j in range(keys.shape[1] - 1, -1, -1)])
+    got = tuple(np.concatenate([p[n] for p in parts])[order] for n in ("keys", "counts", "left", "right"))
+    for g, w in zip(got, want):
+        assert g.shape == w.shape and (g == w).all()
+    assert all(len(p["counts"]) > 0 for p in parts)

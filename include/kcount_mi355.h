@@ -62,9 +62,13 @@ typedef struct kc_config {
   uint64_t max_elems;
   uint32_t flags; /* KC_FLAG_* */
   uint32_t reserved;
-  /* k-mer occurrences the context can hold between kc_reset and kc_finalize on its fast (bucketed)
-   * path; beyond it the context keeps working through its slower global-table path.  Role of the
-   * reference's my_num_kmers estimate (src/contigging.cpp:86).  0 = 64 Mi. */
+  /* k-mer occurrences the context buffers on its fast (bucketed) path.  Sized for the whole input of a pass
+   * (kc_reset .. kc_finalize) the stage runs in one pass, which is what the benchmark measures.  When more arrives,
+   * what is buffered is counted, merged into the global table (one table operation per distinct k-mer) and the
+   * buffer starts again empty: the reference streams 1 MB insert blocks into its one table for as long as reads come
+   * (gpu_hash_table.cpp:681-695).  Correct for any size, but several times slower than one pass (the table then holds
+   * every distinct k-mer, singletons included).  Role of the reference's my_num_kmers estimate
+   * (src/contigging.cpp:86).  0 = 64 Mi. */
   uint64_t max_kmers_buffered;
 } kc_config;
 

@@ -110,6 +110,9 @@ struct kc_ctx {
   Geom gm;
   BucketBufs bb;
   uint64_t *d_cb, *h_cb;
+  bool bk_spilled;       // earlier buffer-fulls of this pass were counted and merged into the global table (bk_spill_pass)
+  uint64_t expect_base;  // CTR_EXPECT when the buffer was last emptied: what is buffered now is CTR_EXPECT - expect_base
+  uint64_t expect_prev;  // CTR_EXPECT after the previous block
   uint64_t bk_capacity;  // records the level-1 segments are sized for
   uint64_t bk_buffered;  // upper bound of records buffered so far (positions submitted)
   uint32_t bk_rot;       // first writer of the next level-1 launch
@@ -511,6 +514,8 @@ extern "C" int kc_reset(kc_ctx *c, int new_k) {
   }
   HIPCHK(hipMemsetAsync(c->d_cb, 0, CB_COUNT * 8, c->stream));
   c->bk_level2 = c->bk_flagged = c->table_mode = c->started = false;
+  c->bk_spilled = false;
+  c->expect_base = c->expect_prev = 0;
   shard_reset(c, c->nl != old_nl || (c->nl == 1 && new_k != old_k));
   HIPCHK(hipStreamSynchronize(c->stream));
   return KC_OK;
@@ -932,6 +937,7 @@ static int bk_drain_to_table(kc_ctx *c) {
 }
 
 static bool bk_active(const kc_ctx *c) { return c->tuning.mode != 1 && !c->table_mode; }
+static int bk_spill_pass(kc_ctx *c);
 // A shard of several that has started the shard flow owns level-1 buckets, not hash values: the entry points that test
 // ownership per k-mer (kc_submit_*, kc_insert_records) would put records where its level 2 never looks.
 static bool shard_flow_only(const kc_ctx *c) { return c->sh.flow && c->cfg.rank_n > 1; }
@@ -996,7 +1002,19 @@ static int run_extract_device(kc_ctx *c, const uint8_t *bases, const uint8_t *qu
       if (rc) return rc;
       if (c->h_ctrs[CTR_BAD_BASE]) return KC_ERR_BAD_BASE;
       // the stats kernel of this block has run: CTR_EXPECT counts every occurrence submitted so far, this block included
-      over_capacity = c->h_ctrs[CTR_EXPECT] > c->bk_capacity;
+      const uint64_t total = c->h_ctrs[CTR_EXPECT];
+      over_capacity = total - c->expect_base > c->bk_capacity;
+      // The buffer cannot take this block on top of what it holds: count what it holds now, merge the counted k-mers
+      // into the global table and go on with an empty buffer on the fast path (the reference streams insert blocks of
+      // 1 MB into its one table for as long as reads come, gpu_hash_table.cpp:681-695).  A block that is too large for
+      // the whole buffer takes the table path as before.
+      if (over_capacity && !c->sh.flow && c->expect_prev > c->expect_base && total - c->expect_prev <= c->bk_capacity) {
+        rc = bk_spill_pass(c);
+        if (rc) return rc;
+        c->expect_base = c->expect_prev;
+        over_capacity = false;
+      }
+      c->expect_prev = total;
     }
   }
   int64_t p0 = 0;  // tiles of every launch start here; the bucketed kernels and the table kernel differ in tile span
@@ -1556,7 +1574,16 @@ extern "C" int kc_insert_records(kc_ctx *c, const uint64_t *d_records, uint64_t 
     if (rc) return rc;
     rc = sync_ctrs(c);
     if (rc) return rc;
-    if (c->h_ctrs[CTR_EXPECT] + n > c->bk_capacity) {
+    const uint64_t buffered = c->h_ctrs[CTR_EXPECT] - c->expect_base;
+    bool fits = buffered + n <= c->bk_capacity;
+    if (!fits && buffered && n <= c->bk_capacity) {  // count what is buffered, merge it into the table, go on empty
+      rc = bk_spill_pass(c);
+      if (rc) return rc;
+      c->expect_base = c->h_ctrs[CTR_EXPECT];
+      fits = true;
+    }
+    c->expect_prev = c->h_ctrs[CTR_EXPECT] + n;
+    if (!fits) {
       rc = bk_drain_to_table(c);
       if (rc) return rc;
     } else {
@@ -2201,7 +2228,13 @@ extern "C" int kc_finalize(kc_ctx *c, kc_result *out) {
     int rc = sync_ctrs(c);
     if (rc) return rc;
     if (c->h_ctrs[CTR_BAD_BASE]) return KC_ERR_BAD_BASE;
-    if (c->bk_ready && !c->table_mode) {
+    if (c->bk_ready && !c->table_mode && c->bk_spilled) {  // k-mers may sit both in the table and in the buffer: merge, then the table's finalize
+      rc = bk_spill_pass(c);
+      if (rc) return rc;
+      rc = sync_ctrs(c);
+      if (rc) return rc;
+    }
+    if (c->bk_ready && !c->table_mode && !c->bk_spilled) {
       rc = bk_finalize(c);
       if (rc) return rc;
     } else {
@@ -2290,6 +2323,50 @@ static int bk_dump(kc_ctx *c, uint64_t **dk, uint16_t **dc, uint16_t **de, uint6
   return bk_move_flagged(c);
 }
 
+// The buffer is full and more reads are coming: count what it holds (the regions' entries with their raw counters,
+// like kc_dump_table), add every counted k-mer to the global table in ONE table operation (not one per occurrence:
+// about a seventh of the operations at the benchmark's depth), and start the buffer again empty.  The table is where
+// the passes meet; kc_finalize then runs one last pass and the table's own finalize.
+template <int NL>
+static void launch_merge_entries(kc_ctx *c, const uint64_t *dk, const uint16_t *dc, const uint16_t *de, uint64_t n) {
+  KernelTimer kt(c, KT_INSERT_RECORDS);
+  hipLaunchKernelGGL(kc_merge_entries_kernel<NL>, dim3((unsigned)std::min<uint64_t>((n + TPB - 1) / TPB, 256 * 32)), dim3(TPB), 0, c->stream, dk,
+                     dc, de, n, c->table, c->d_ctrs);
+}
+
+static int bk_spill_pass(kc_ctx *c) {
+  uint64_t *dk = nullptr;
+  uint16_t *dc = nullptr, *de = nullptr;
+  uint64_t n = 0;
+  int rc = bk_dump(c, &dk, &dc, &de, &n);  // regions built, entries listed, flagged regions and overflow records to the table
+  if (!rc && n) {
+    rc = ensure_room(c, n);
+    if (!rc) {
+      switch (c->nl) {
+        case 1: launch_merge_entries<1>(c, dk, dc, de, n); break;
+        case 2: launch_merge_entries<2>(c, dk, dc, de, n); break;
+        case 3: launch_merge_entries<3>(c, dk, dc, de, n); break;
+        default: launch_merge_entries<4>(c, dk, dc, de, n); break;
+      }
+      if (hipGetLastError() != hipSuccess) rc = KC_ERR_HIP;
+    }
+  }
+  if (hipStreamSynchronize(c->stream) != hipSuccess && !rc) rc = KC_ERR_HIP;
+  if (dk) (void)hipFree(dk);
+  if (dc) (void)hipFree(dc);
+  if (de) (void)hipFree(de);
+  if (rc) return rc;
+  const size_t R = (size_t)c->gm.P1 * c->gm.P2;
+  HIPCHK(hipMemsetAsync(c->bb.cnt1, 0, (size_t)c->gm.G * c->gm.P1 * 4, c->stream));
+  HIPCHK(hipMemsetAsync(c->bb.used1, 0, (size_t)c->gm.G * 4, c->stream));
+  HIPCHK(hipMemsetAsync(c->bb.cnt2, 0, R * 4, c->stream));
+  HIPCHK(hipMemsetAsync(c->bb.flag, 0, R * 4, c->stream));
+  HIPCHK(hipMemsetAsync(c->d_cb, 0, CB_COUNT * 8, c->stream));
+  c->bk_level2 = c->bk_flagged = false;
+  c->bk_spilled = true;
+  return KC_OK;
+}
+
 // n keys from a device array of the library's width to a host array of the reference's width
 static int keys_to_host(kc_ctx *c, uint64_t *h_dst, const uint64_t *d_src, uint64_t n) {
   if (!n) return KC_OK;
@@ -2316,7 +2393,12 @@ extern "C" int kc_dump_table(kc_ctx *c, uint64_t *keys, uint16_t *counts, uint16
   uint64_t *rk = nullptr;
   uint16_t *rc16 = nullptr, *re = nullptr;
   uint64_t nreg = 0;
-  if (c->bk_ready && !c->table_mode) {
+  if (c->bk_ready && !c->table_mode && c->bk_spilled) {  // one k-mer, one entry: what is buffered joins the table first
+    rc = bk_spill_pass(c);
+    if (rc) return rc;
+    rc = sync_ctrs(c);
+    if (rc) return rc;
+  } else if (c->bk_ready && !c->table_mode) {
     rc = bk_dump(c, &rk, &rc16, &re, &nreg);
     if (rc) return rc;
     rc = sync_ctrs(c);

@@ -97,18 +97,13 @@ __device__ __forceinline__ void sat_inc(uint32_t *p) {
   if (old >= 0x80000000u) atomicSub(p, 1u);  // far above 65535 already; keeps the u32 from wrapping
 }
 
-// Insert one record (canonical k-mer + extension codes).  Linear probing, power-of-two capacity;
-// the host keeps the load below 0.9 by growing the table, so the probe always terminates and
+// The slot of a canonical k-mer (extension bits cleared), claimed if the k-mer is new.  Linear probing, power-of-two
+// capacity; the host keeps the load below 0.9 by growing the table, so the probe always terminates and
 // nothing is ever dropped (the reference drops after KCOUNT_HT_MAX_PROBE, kcount_cpu.cpp:232-268).
 template <int NL>
-__device__ __forceinline__ void table_insert(const Table &t, const uint64_t (&rec)[NL], uint64_t *ctrs) {
-  uint64_t key[NL];
-#pragma unroll
-  for (int j = 0; j < NL; j++) key[j] = rec[j];
-  const uint32_t le = (uint32_t)(rec[NL - 1] & 7u), re = (uint32_t)((rec[NL - 1] >> 3) & 7u);
-  key[NL - 1] &= ~KC_EXT_MASK;
+__device__ __forceinline__ uint64_t table_slot(const Table &t, const uint64_t (&key)[NL], bool &is_new) {
   uint64_t slot = kc_hash<NL>(key) & t.mask;
-  bool is_new = false;
+  is_new = false;
   if constexpr (NL == 1) {
     for (;;) {
       // plain load as a hint: a slot only ever goes EMPTY -> key, so a stale line can only claim
@@ -153,11 +148,48 @@ __device__ __forceinline__ void table_insert(const Table &t, const uint64_t (&re
       done = done || won || same;
     } while (__any(!done));
   }
+  return slot;
+}
+
+// Insert one record (canonical k-mer + extension codes).
+template <int NL>
+__device__ __forceinline__ void table_insert(const Table &t, const uint64_t (&rec)[NL], uint64_t *ctrs) {
+  uint64_t key[NL];
+#pragma unroll
+  for (int j = 0; j < NL; j++) key[j] = rec[j];
+  const uint32_t le = (uint32_t)(rec[NL - 1] & 7u), re = (uint32_t)((rec[NL - 1] >> 3) & 7u);
+  key[NL - 1] &= ~KC_EXT_MASK;
+  bool is_new;
+  const uint64_t slot = table_slot<NL>(t, key, is_new);
   uint32_t *v = t.vals + slot * 9;
   sat_inc(v);                              // S6 count
   if (le < 4u) sat_inc(v + 1 + le);        // S5/S6 only ACGT extensions are counted
   if (re < 4u) sat_inc(v + 5 + re);
   if (is_new) atomicAdd((unsigned long long *)&ctrs[CTR_ENTRIES], 1ULL);
+}
+
+// Add an already counted k-mer (its occurrences and its eight extension counters, each clipped to 65535 by whoever
+// counted them: a sum of clipped values clips to the same 65535 as the sum of the unclipped ones, S6).
+__device__ __forceinline__ void sat_add(uint32_t *p, uint32_t x) {
+  if (!x) return;
+  const uint32_t old = atomicAdd(p, x);
+  if (old >= 0x80000000u) atomicSub(p, x);  // far above 65535 already; keeps the u32 from wrapping
+}
+template <int NL>
+__global__ __launch_bounds__(TPB) void kc_merge_entries_kernel(const uint64_t *keys, const uint16_t *counts, const uint16_t *exts, uint64_t n,
+                                                               Table t, uint64_t *ctrs) {
+  for (uint64_t i = (uint64_t)blockIdx.x * TPB + threadIdx.x; i < n; i += (uint64_t)gridDim.x * TPB) {
+    uint64_t key[NL];
+#pragma unroll
+    for (int j = 0; j < NL; j++) key[j] = keys[i * NL + j];
+    bool is_new;
+    const uint64_t slot = table_slot<NL>(t, key, is_new);
+    uint32_t *v = t.vals + slot * 9;
+    sat_add(v, counts[i]);
+#pragma unroll
+    for (int x = 0; x < 8; x++) sat_add(v + 1 + x, exts[i * 8 + x]);
+    if (is_new) atomicAdd((unsigned long long *)&ctrs[CTR_ENTRIES], 1ULL);
+  }
 }
 
 // ---- tile staging --------------------------------------------------------------------------

@@ -374,6 +374,59 @@ def test_full_buffer_falls_back_to_the_table_path():
     assert st["num_unique"] == wst["unique"] and st["kmers_inserted"] == wst["kmers_inserted"]
 
 
+@pytest.mark.parametrize("k,tuning", [(21, None), (21, dict(writers=3, p1=256, p2=256, slots=512)), (33, dict(ovf_capacity=1 << 16)),
+                                      (77, dict(writers=3, p1=4, p2=8, slots=512, ovf_capacity=1 << 16))],  # (the lists of so small a buffer would not hold one tile)
+                         ids=["k21", "k21-compact", "k33", "k77-small"])
+def test_a_full_buffer_is_counted_and_merged_not_abandoned(k, tuning):
+    """More reads than max_kmers_buffered holds: every time the buffer is full its k-mers are counted, merged into the
+    global table (one table operation per distinct k-mer) and the buffer starts again empty -- the context stays on the
+    fast path (the reference streams insert blocks into its one table indefinitely, gpu_hash_table.cpp:681-695).
+    Several passes, a pre-purge dump in the middle of it all, the result bit-exact."""
+    reads, quals = _reads_for_overflow(50 + k, n=2400)
+    b, q, offs = arrays(reads, quals)
+    want, wtable, wst = oracle_run(b, q, offs, k)
+    per_block = sum(max(0, len(r) - k - 1) for r in reads[:300])
+    with pkg.KmerCounter(k, max_kmers_buffered=int(per_block * 2.5), tuning=tuning, time_kernels=True) as kc:  # two blocks fit, the third does not
+        for r0 in range(0, 2400, 300):
+            bb, qq, oo = arrays(reads[r0:r0 + 300], quals[r0:r0 + 300])
+            kc.submit_reads(bb, qq, oo)
+        gtable = kc.dump_table()
+        got = kc.sorted_results()
+        st = kc.stats()
+        kt = kc.kernel_times()
+    assert_same(got, want)
+    assert (gtable[0] == wtable[0]).all() and (gtable[1] == wtable[1]).all() and (gtable[2] == wtable[2]).all()
+    assert st["num_unique"] == wst["unique"] and st["num_purged"] == wst["purged"] and st["sum_counts"] == wst["sum_counts"]
+    assert st["kmers_inserted"] == wst["kmers_inserted"]
+    # the reads went through level 1 every time (no launch of the global-table extraction kernel), in several passes
+    assert "kc_extract_kernel<insert>" not in kt and kt["kc_l2_split_kernel"][0] >= 3
+
+
+def test_records_path_spills_a_full_buffer_too():
+    k, R = 21, 2
+    rng = np.random.default_rng(23)
+    reads, quals = random_reads(rng, 1600, min_len=30, max_len=150, genome_len=3000)
+    b, q, offs = arrays(reads, quals)
+    want, _, wst = oracle_run(b, q, offs, k)
+    import torch
+    total = int(wst["kmers_inserted"])
+    shards = [pkg.KmerCounter(k, rank_me=r, rank_n=R, max_kmers_buffered=total // 6, time_kernels=True) for r in range(R)]
+    recs = torch.zeros(R * total, dtype=torch.int64, device="cuda")
+    for r0 in range(0, 1600, 200):  # eight blocks of about total / 8 records, half of each per shard
+        bb, qq, oo = arrays(reads[r0:r0 + 200], quals[r0:r0 + 200])
+        counts = shards[0].extract_partition(bb, qq, oo, recs, total)
+        for d in range(R):
+            shards[d].insert_records(recs[d * total:], int(counts[d]))
+    parts = [s.sorted_results() for s in shards]
+    keys = np.concatenate([p[0] for p in parts])
+    order = np.lexsort([keys[:, 0]])
+    assert_same(tuple(np.concatenate([p[i] for p in parts])[order] for i in range(4)), want)
+    for s in shards:
+        kt = s.kernel_times()
+        assert kt["kc_l2_split_kernel"][0] >= 2  # more than one pass
+        s.close()
+
+
 def test_heavy_hitter_kmers():
     # one k-mer in almost every read: a region far above its mean size, counters far above the rest
     k = 21

@@ -600,6 +600,8 @@ static int pick_fast_arena(kc_ctx *c, uint64_t **arena, size_t bytes, uint32_t G
   return KC_OK;
 }
 
+constexpr double KC_MAX_REGION_LOAD = 0.72;  // highest mean load of the region tables bk_init plans with
+
 // Choose the geometry from the configured sizes and allocate the level-1 / level-2 arenas.
 static int bk_init(kc_ctx *c) {
   if (c->bk_ready) return KC_OK;
@@ -617,11 +619,13 @@ static int bk_init(kc_ctx *c) {
   // longest probe, and the count kernel's time grows steeply with the load (measured: 1.6x from 0.4 to 0.6), more
   // than the per-region costs (barriers, the exposed latency of the first loads) shrink with fewer, fuller regions.
   // Half-size tables let two region workgroups share a CU (one's barriers and scans overlap the other's inserts:
-  // measured 10 % faster counting), so prefer them while 2^20 regions of them stay under 0.55 load.
+  // measured 10 % faster counting; k=51 at 0.68 load: 28 ms against 36 ms for the full-size tables at 0.34), so prefer
+  // them while 2^20 regions of them stay under KC_MAX_REGION_LOAD (a region's distinct k-mers scatter by a few
+  // per cent around the mean: 0.72 leaves 15 standard deviations of room at these sizes).
   g.S = t.slots ? std::min(std::max(t.slots, 16u), smax) : smax;
   while (g.S & (g.S - 1)) g.S &= g.S - 1;  // power of two (round down)
   const double target_load = 0.4;
-  if (!t.slots && est <= 0.55 * (double)(1u << 20) * (g.S / 2)) g.S /= 2;
+  if (!t.slots && est <= KC_MAX_REGION_LOAD * (double)(1u << 20) * (g.S / 2)) g.S /= 2;
   const uint64_t regions_needed = std::min<uint64_t>((uint64_t)(est / (target_load * g.S)) + 1, 1ULL << 20);
   // the two fan-outs multiply to the number of regions; any value up to 1024 each (the hash fields are mapped by
   // multiply-shift), level 1 the smaller one because it holds fewer records per round
@@ -1848,7 +1852,7 @@ extern "C" int kc_shard_capacity(kc_ctx *c, uint64_t *max_distinct) {
   if (rc) return rc;
   const uint32_t n = (uint32_t)c->cfg.rank_n, me = (uint32_t)c->cfg.rank_me;
   const uint64_t mine = shard_first_bucket(me + 1, c->gm.P1, n) - shard_first_bucket(me, c->gm.P1, n);
-  *max_distinct = (uint64_t)(0.55 * (double)(mine * c->gm.P2) * (double)c->gm.S);  // the load bk_init accepts
+  *max_distinct = (uint64_t)(KC_MAX_REGION_LOAD * (double)(mine * c->gm.P2) * (double)c->gm.S);  // the load bk_init accepts
   return KC_OK;
 }
 

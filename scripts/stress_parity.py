@@ -4,6 +4,7 @@ import os, sys
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 sys.path.insert(0, os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "tests"))
 import numpy as np
+import torch  # before the library touches the device
 import mhm2_kmer_analysis_v2_amd as pkg
 from oracle import cpu_oracle as O
 from helpers import random_reads
@@ -12,7 +13,7 @@ cases = int(sys.argv[1]) if len(sys.argv) > 1 else 40
 seed = int(sys.argv[2]) if len(sys.argv) > 2 else 1
 scale = int(sys.argv[3]) if len(sys.argv) > 3 else 1  # multiplies the number of reads and the genome length
 rng = np.random.default_rng(seed)
-KS = [11, 13, 15, 17, 19, 21, 23, 25, 27, 29, 33, 47, 51, 61, 65, 77, 93]  # k % 32 in {30, 31} is rejected by the library
+KS = [11, 13, 15, 17, 19, 21, 23, 25, 27, 29, 30, 31, 33, 47, 51, 61, 62, 63, 65, 77, 93, 95]
 bad = 0
 for c in range(cases):
     k = int(rng.choice(KS))
@@ -37,21 +38,55 @@ for c in range(cases):
                  chain1_max=int(rng.integers(4, 40)), chain2_max=int(rng.integers(4, 40)), ovf_capacity=1 << 20)
     elif tuning == "wide":
         t = dict(mode=2, p1=1 << min(la, 8), p2=1 << min(lb, 8))
+    occ = sum(max(0, len(r) - k - 1) for r in reads)
+    flow = rng.choice(["plain", "plain", "small-buffer", "shards"])
+    if flow == "small-buffer" and t is not None:
+        t["ovf_capacity"] = 1 << 20  # (the lists of a tiny buffer would not hold one tile)
     try:
-        with pkg.KmerCounter(k, max_kmers_buffered=(1 << 22) * scale, tuning=t) as kc:
-            nb = int(rng.integers(1, 4))  # submit in several pieces
-            cuts = sorted(set([0, nreads] + [int(x) for x in rng.integers(0, nreads + 1, size=nb - 1)]))
-            for a0, a1 in zip(cuts[:-1], cuts[1:]):
-                bb, qq, oo = O.reads_to_arrays(reads[a0:a1], quals[a0:a1])
-                if a1 > a0:
-                    kc.submit_reads(bb, qq, oo)
-            got = kc.sorted_results()
+        if flow == "shards":
+            R = int(rng.integers(2, 5))
+            if t is not None and t.get("p1", 1024) < R:
+                t["p1"] = 8
+            shards = [pkg.KmerCounter(k, rank_me=r, rank_n=R, max_kmers_buffered=(1 << 22) * scale, tuning=t) for r in range(R)]
+            nl = shards[0].rec_nl
+            seg_words = occ * nl + 4096
+            segs = torch.zeros(R * seg_words, dtype=torch.int64, device="cuda")
+            nb = int(rng.integers(1, 4))
+            for r in range(R):
+                mine = list(range(r, nreads, R))
+                for piece in range(nb):
+                    part = mine[piece * len(mine) // nb:(piece + 1) * len(mine) // nb]
+                    bb, qq, oo = O.reads_to_arrays([reads[i] for i in part], [quals[i] for i in part])
+                    words = shards[r].shard_extract(bb, qq, oo, segs, seg_words)
+                    for d in range(R):
+                        w = int(words[d])
+                        if d != r and w:
+                            dst = shards[d].shard_reserve(w)
+                            dst.copy_(segs[d * seg_words:d * seg_words + w])
+                            torch.cuda.synchronize()
+                            shards[d].shard_commit(dst, w)
+            parts = [sh.sorted_results() for sh in shards]
+            for sh in shards:
+                sh.close()
+            keys = np.concatenate([p[0] for p in parts])
+            order = np.lexsort([keys[:, j] for j in range(keys.shape[1] - 1, -1, -1)])
+            got = tuple(np.concatenate([p[i] for p in parts])[order] for i in range(4))
+        else:
+            cap = (1 << 22) * scale if flow == "plain" else max(40000, int(occ * float(rng.choice([0.3, 0.6, 1.5]))))
+            with pkg.KmerCounter(k, max_kmers_buffered=cap, tuning=t) as kc:
+                nb = int(rng.integers(1, 4)) if flow == "plain" else int(rng.integers(3, 9))  # submit in several pieces
+                cuts = sorted(set([0, nreads] + [int(x) for x in rng.integers(0, nreads + 1, size=nb - 1)]))
+                for a0, a1 in zip(cuts[:-1], cuts[1:]):
+                    bb, qq, oo = O.reads_to_arrays(reads[a0:a1], quals[a0:a1])
+                    if a1 > a0:
+                        kc.submit_reads(bb, qq, oo)
+                got = kc.sorted_results()
         ok = all(g.shape == w.shape and (g == w).all() for g, w in zip(got, want))
     except Exception as e:  # noqa
         ok = False
         print("  exception:", repr(e))
     if not ok:
         bad += 1
-    print("case %d k=%d reads=%d genome=%d tuning=%s %s -> %s (%d k-mers)" % (c, k, nreads, genome, tuning, t, "ok" if ok else "MISMATCH", len(want[1])), flush=True)
+    print("case %d k=%d reads=%d genome=%d %s tuning=%s %s -> %s (%d k-mers)" % (c, k, nreads, genome, flow, tuning, t, "ok" if ok else "MISMATCH", len(want[1])), flush=True)
 print("mismatches:", bad)
 sys.exit(1 if bad else 0)

@@ -228,6 +228,9 @@ int kc_insert_records(kc_ctx *ctx, const uint64_t *d_records, uint64_t n);
  * hold more than max_kmers_buffered. */
 int kc_shard_extract(kc_ctx *ctx, const uint8_t *bases, const uint8_t *quals, const uint64_t *offsets, uint64_t nreads, int on_device,
                      uint64_t *d_segments, uint64_t seg_words, uint64_t *h_words);
+/* The same for a '_'-joined, case-masked block (the format ParseAndPackGPUDriver::process_seq_block takes). */
+int kc_shard_extract_seq_block(kc_ctx *ctx, const char *seqs, uint64_t len, int on_device, uint64_t *d_segments, uint64_t seg_words,
+                               uint64_t *h_words);
 /* Receiver: device memory of the context for `nwords` incoming words (the sum over the senders of one block; the caller
  * receives each sender's segment into its own 2-word-aligned part of it).  It belongs to the context and stays valid
  * until kc_reset / kc_destroy; earlier reservations never move. */

@@ -79,6 +79,7 @@ SYMBOLS = {
     "kc_extract_partition_seq_block": (C.c_int, [C.c_void_p, C.c_void_p, C.c_uint64, C.c_int, C.c_void_p, C.c_uint64, C.c_void_p]),
     "kc_insert_records": (C.c_int, [C.c_void_p, C.c_void_p, C.c_uint64]),
     "kc_shard_extract": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_uint64, C.c_int, C.c_void_p, C.c_uint64, C.c_void_p]),
+    "kc_shard_extract_seq_block": (C.c_int, [C.c_void_p, C.c_void_p, C.c_uint64, C.c_int, C.c_void_p, C.c_uint64, C.c_void_p]),
     "kc_shard_reserve": (C.c_int, [C.c_void_p, C.c_uint64, C.POINTER(C.c_void_p)]),
     "kc_shard_commit": (C.c_int, [C.c_void_p, C.c_void_p, C.c_uint64]),
     "kc_shard_owner": (C.c_int, [C.c_void_p, C.c_void_p, C.POINTER(C.c_int)]),

@@ -1382,7 +1382,7 @@ extern "C" int kc_fastq_to_packed(const char *text, uint64_t len, int qual_offse
 
 extern "C" int kc_submit_seq_block(kc_ctx *c, const char *seqs, uint64_t len, int on_device) {
   if (!c || (len && !seqs)) return KC_ERR_INVALID_ARG;
-  if (c->finalized || c->bk_level2 || shard_flow_only(c)) return KC_ERR_STATE;
+  if (c->finalized || c->bk_level2 || (shard_flow_only(c) && !c->sh.extracting)) return KC_ERR_STATE;
   HIPCHK(hipSetDevice(c->cfg.device));
   if (!len) return KC_OK;
   const uint8_t *d = (const uint8_t *)seqs;
@@ -1657,10 +1657,10 @@ static void launch_shard_loose(kc_ctx *c, const uint64_t *recs, uint64_t n) {
                      c->table, c->d_ctrs);
 }
 
-extern "C" int kc_shard_extract(kc_ctx *c, const uint8_t *bases, const uint8_t *quals, const uint64_t *offsets, uint64_t nreads, int on_device,
-                                uint64_t *d_segments, uint64_t seg_words, uint64_t *h_words) {
+// checks and set-up shared by the two forms of kc_shard_extract
+static int shard_extract_begin(kc_ctx *c, uint64_t *d_segments, uint64_t seg_words, uint64_t *h_words) {
   if (!c || !h_words) return KC_ERR_INVALID_ARG;
-  const uint32_t n = (uint32_t)c->cfg.rank_n, me = (uint32_t)c->cfg.rank_me;
+  const uint32_t n = (uint32_t)c->cfg.rank_n;
   if (n > 1 && (!d_segments || seg_words < SHARD_HDR + PMAX / 2)) return KC_ERR_INVALID_ARG;
   for (uint32_t d = 0; d < n; d++) h_words[d] = 0;
   if (c->finalized || c->bk_level2) return KC_ERR_STATE;
@@ -1679,12 +1679,14 @@ extern "C" int kc_shard_extract(kc_ctx *c, const uint8_t *bases, const uint8_t *
     snprintf(g_last_error, sizeof(g_last_error), "more shards (%u) than level-1 buckets (%u)", n, c->gm.P1);
     return KC_ERR_INVALID_ARG;
   }
-  c->sh.flow = true;
-  c->sh.extracting = true;
-  rc = submit_reads_impl(c, bases, quals, offsets, nreads, on_device, MODE_INSERT, nullptr, 0);
-  c->sh.extracting = false;
-  if (rc) return rc;
-  if (n == 1 || !nreads) return KC_OK;  // a single shard owns every bucket: nothing leaves
+  return KC_OK;
+}
+
+// after level 1 has taken the block: what other shards own leaves the chains for the wire segments
+static int shard_extract_pack(kc_ctx *c, bool anything, uint64_t *d_segments, uint64_t seg_words, uint64_t *h_words) {
+  const uint32_t n = (uint32_t)c->cfg.rank_n, me = (uint32_t)c->cfg.rank_me;
+  int rc;
+  if (n == 1 || !anything) return KC_OK;  // a single shard owns every bucket: nothing leaves
   rc = shard_init(c);
   if (rc) return rc;
   uint64_t *off = c->sh.d_plan, *totals = off + PMAX, *flags = totals + SHARD_MAX, *loose = flags + SHARD_MAX;
@@ -1746,6 +1748,30 @@ extern "C" int kc_shard_extract(kc_ctx *c, const uint8_t *bases, const uint8_t *
     c->sh.sent += h_totals[d] + h_loose[d];
   }
   return KC_OK;
+}
+
+extern "C" int kc_shard_extract(kc_ctx *c, const uint8_t *bases, const uint8_t *quals, const uint64_t *offsets, uint64_t nreads, int on_device,
+                                uint64_t *d_segments, uint64_t seg_words, uint64_t *h_words) {
+  int rc = shard_extract_begin(c, d_segments, seg_words, h_words);
+  if (rc) return rc;
+  c->sh.flow = true;
+  c->sh.extracting = true;
+  rc = submit_reads_impl(c, bases, quals, offsets, nreads, on_device, MODE_INSERT, nullptr, 0);
+  c->sh.extracting = false;
+  if (rc) return rc;
+  return shard_extract_pack(c, nreads != 0, d_segments, seg_words, h_words);
+}
+
+extern "C" int kc_shard_extract_seq_block(kc_ctx *c, const char *seqs, uint64_t len, int on_device, uint64_t *d_segments, uint64_t seg_words,
+                                          uint64_t *h_words) {
+  int rc = shard_extract_begin(c, d_segments, seg_words, h_words);
+  if (rc) return rc;
+  c->sh.flow = true;
+  c->sh.extracting = true;
+  rc = kc_submit_seq_block(c, seqs, len, on_device);
+  c->sh.extracting = false;
+  if (rc) return rc;
+  return shard_extract_pack(c, len != 0, d_segments, seg_words, h_words);
 }
 
 extern "C" int kc_shard_reserve(kc_ctx *c, uint64_t nwords, uint64_t **d_dst) {

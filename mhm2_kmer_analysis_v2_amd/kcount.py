@@ -194,6 +194,18 @@ class KmerCounter:
         check(lib().kc_shard_extract(self._h, pb, pq, po, n, 1 if dev else 0, ps, seg_words, words.ctypes.data), "kc_shard_extract")
         return words
 
+    def shard_extract_seq_block(self, seqs, segments, seg_words):
+        """The same from a '_'-joined case-masked block (bytes, or a device tensor of them)."""
+        if isinstance(seqs, (bytes, bytearray)):
+            buf = np.frombuffer(bytes(seqs), dtype=np.uint8)
+            p, dev, n = buf.ctypes.data, False, len(buf)
+        else:
+            (p, dev), n = _ptr(seqs), len(seqs)
+        ps, _ = _ptr(segments)
+        words = np.zeros(self.rank_n, dtype=np.uint64)
+        check(lib().kc_shard_extract_seq_block(self._h, p, n, 1 if dev else 0, ps, seg_words, words.ctypes.data), "kc_shard_extract_seq_block")
+        return words
+
     def shard_reserve(self, nwords, device=None):
         """Context-owned device memory for nwords incoming u64, as an int64 torch tensor viewing it (no copy)."""
         import torch

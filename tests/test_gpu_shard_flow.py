@@ -210,3 +210,33 @@ def test_shard_capacity_follows_the_geometry():
     assert c1 >= est                 # a single shard owns every region of a geometry made for est
     assert cp * 3 < c1               # a quarter of the same geometry
     assert cf >= est                 # the flag makes the geometry four times as large: the quarter holds est again
+
+
+@pytest.mark.parametrize("k,R", [(21, 2), (51, 3)])
+def test_shard_flow_from_seq_blocks(k, R):
+    """kc_shard_extract_seq_block: the reference's '_'-joined case-masked block as the sender's input."""
+    import torch
+    rng = np.random.default_rng(61 + k)
+    reads, quals = random_reads(rng, 900, min_len=30, max_len=150, genome_len=2500)
+    b, q, offs = arrays(reads, quals)
+    want, _, _ = oracle_run(b, q, offs, k)
+    masked = ["".join(c.lower() if ord(x) < 33 + 20 else c for c, x in zip(r, ql)) for r, ql in zip(reads, quals)]
+    shards = [pkg.KmerCounter(k, rank_me=r, rank_n=R, tuning=PATHS["compact"] if k == 21 else None) for r in range(R)]
+    nl = shards[0].rec_nl
+    seg_words = sum(max(0, len(r) - k - 1) for r in reads) * nl + 2048
+    segs = torch.zeros(R * seg_words, dtype=torch.int64, device="cuda")
+    for r in range(R):
+        for piece in range(2):
+            part = masked[r::R][piece::2]
+            words = shards[r].shard_extract_seq_block("_".join(part).encode(), segs, seg_words)
+            for d in range(R):
+                w = int(words[d])
+                if d == r or not w:
+                    continue
+                dst = shards[d].shard_reserve(w)
+                dst.copy_(segs[d * seg_words:d * seg_words + w])
+                torch.cuda.synchronize()
+                shards[d].shard_commit(dst, w)
+    assert_same(union([s.sorted_results() for s in shards]), want)
+    for s in shards:
+        s.close()

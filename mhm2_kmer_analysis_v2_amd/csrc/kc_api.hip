@@ -548,11 +548,11 @@ static uint32_t ilog2(uint64_t v) {
 }
 
 // The same split kernel on the same virtual addresses runs at different speeds on different ALLOCATIONS of its arena:
-// level 1 in 30-32 ms on one, in 36 ms or in 40 ms on another, level 2 in 26.8 or 27.8 ms (measured,
+// level 1 in 30-32 ms on one, in 36 ms or in 40 ms on another (measured,
 // scripts/l1_mode_probe.py and scripts/probe_runs.sh: fixed for the life of the allocation; how the driver backed the
 // memory is the suspect).  One millisecond of the kernels' write pattern alone -- every workgroup appending 64-byte runs
-// round-robin to 1024 open chunks of its own part (kc_arena_probe_kernel) -- tells the allocations apart: 4.3 GB at
-// >= 4.9 TB/s on a fast arena, 3.6-4.3 TB/s on a slow one.  Freeing a slow arena and asking again tends to return the
+// round-robin to a window of 1024 open chunks that jumps through its whole part (kc_arena_probe_kernel) -- tells the
+// allocations apart: 4.3 GB at >= 4.8 TB/s on a fast arena, 3.6-4.3 TB/s on a slow one.  Freeing a slow arena and asking again tends to return the
 // same memory, so a slow one is HELD while another is asked for (when the device has the room), at most four in all;
 // the fastest is kept.  KC_ARENA_PROBE=0 switches this off, =1 logs.
 static int pick_fast_arena(kc_ctx *c, uint64_t **arena, size_t bytes, uint32_t G, const char *what) {
@@ -705,9 +705,8 @@ static int bk_init(kc_ctx *c) {
   {
     const char *pe = getenv("KC_ARENA_PROBE");
     if (!(pe && pe[0] == '0') && g.G >= (uint32_t)c->num_cus && (size_t)g.A1 * CH1 * c->nl >= ((size_t)8 << 20)) {  // the benchmark's sizes
+      // (level 2's arena was tried too: its probe does not predict level 2's time, which moves by only 4 %)
       int rc = pick_fast_arena(c, &b.rec1, rec1_bytes, g.G, "level 1");
-      if (rc) return rc;
-      rc = pick_fast_arena(c, reinterpret_cast<uint64_t **>(&b.rec2), rec2_bytes, g.G, "level 2");
       if (rc) return rc;
     }
   }

@@ -393,17 +393,20 @@ __device__ __forceinline__ ChainState split_load_state(SplitLDS &L, uint32_t P, 
 }
 
 // ---- how fast does this arena take level 1's write pattern? -------------------------------------------------------------
-// Every workgroup appends 64-byte runs round-robin to 1024 open chunks of its own part of the arena, the chunks taken
-// bump-style like a writer's: level 1's stores without the rest of level 1 (bk_init times it, see there).
+// Every workgroup appends 64-byte runs round-robin to 1024 open chunks of its own part of the arena, like a writer of
+// level 1 -- its stores without the rest of it (pick_fast_arena times it).  The window of open chunks jumps through the
+// workgroup's whole part (32 places, eight rounds at each): an arena can be slow in places.
 __global__ __launch_bounds__(WGB) void kc_arena_probe_kernel(uint64_t *arena, size_t words_per_wg, uint32_t rounds) {
   uint64_t *mine = arena + (size_t)blockIdx.x * words_per_wg;
   const uint32_t t = threadIdx.x, b = t >> 3, w = t & 7u;  // eight lanes write one 64-byte run
+  const size_t chunks = words_per_wg / 512u;               // 512-record chunks in this part
+  const size_t hop = chunks > 1024u ? (chunks - 1024u) / 31u : 0u;
   for (uint32_t r = 0; r < rounds; r++) {
+    const size_t first = (size_t)((r >> 3) & 31u) * hop;   // where the window of 1024 open chunks starts
 #pragma unroll
     for (uint32_t j = 0; j < 8; j++) {
-      const uint32_t bucket = b + 128u * j;                                   // 1024 buckets per round
-      const size_t chunk = (size_t)bucket + 1024u * (size_t)(r >> 6);         // 512-record chunks: a new one every 64 rounds
-      const size_t at = chunk * 512u + (size_t)(r & 63u) * 8u + w;
+      const size_t chunk = first + b + 128u * j;           // 1024 chunks per round
+      const size_t at = chunk * 512u + (size_t)(r & 7u) * 8u + w;
       if (at < words_per_wg) mine[at] = (uint64_t)r;
     }
   }

@@ -553,8 +553,10 @@ static uint32_t ilog2(uint64_t v) {
 // memory is the suspect).  One millisecond of the kernels' write pattern alone -- every workgroup appending 64-byte runs
 // round-robin to a window of 1024 open chunks that jumps through its whole part (kc_arena_probe_kernel) -- tells the
 // allocations apart: 4.3 GB at >= 4.8 TB/s on a fast arena, 3.6-4.3 TB/s on a slow one.  Freeing a slow arena and asking again tends to return the
-// same memory, so a slow one is HELD while another is asked for (when the device has the room), at most four in all;
-// the fastest is kept.  KC_ARENA_PROBE=0 switches this off, =1 logs.
+// same memory: a slow one is first written from end to end, freed and asked for again (which brings most of them back
+// fast), and if that does not help it is HELD while another is asked for (when the device has the room), at most four
+// in all; the fastest is kept.  First processes on a freshly started box draw slow arenas most often.
+// KC_ARENA_PROBE=0 switches this off, =1 logs.
 static int pick_fast_arena(kc_ctx *c, uint64_t **arena, size_t bytes, uint32_t G, const char *what) {
   const char *pe = getenv("KC_ARENA_PROBE");
   hipEvent_t e0, e1;
@@ -566,23 +568,43 @@ static int pick_fast_arena(kc_ctx *c, uint64_t **arena, size_t bytes, uint32_t G
   constexpr int NCAND = 4;
   uint64_t *cand[NCAND] = {*arena, nullptr, nullptr, nullptr};
   double rate[NCAND] = {0, 0, 0, 0};
-  int ncand = 1, best_i = 0;
-  for (int i = 0; i < NCAND; i++) {
+  int ncand = 1;
+  auto probe = [&](uint64_t *p) -> double {  // TB/s of the write pattern on p, the better of two runs; < 0: a HIP call failed
     float best = 1e30f;
     for (int rep = 0; rep < 2; rep++) {
-      HIPCHK(hipEventRecord(e0, c->stream));
-      hipLaunchKernelGGL(kc_arena_probe_kernel, dim3(G), dim3(WGB), 0, c->stream, cand[i], wpw, rounds);
-      HIPCHK(hipEventRecord(e1, c->stream));
-      HIPCHK(hipEventSynchronize(e1));
       float ms = 0;
-      HIPCHK(hipEventElapsedTime(&ms, e0, e1));
+      if (hipEventRecord(e0, c->stream) != hipSuccess) return -1.0;
+      hipLaunchKernelGGL(kc_arena_probe_kernel, dim3(G), dim3(WGB), 0, c->stream, p, wpw, rounds);
+      if (hipEventRecord(e1, c->stream) != hipSuccess || hipEventSynchronize(e1) != hipSuccess || hipEventElapsedTime(&ms, e0, e1) != hipSuccess)
+        return -1.0;
       best = std::min(best, ms);
     }
-    rate[i] = probe_bytes / (best * 1e-3) / 1e12;
-    if (rate[i] > rate[best_i]) best_i = i;
-    if (pe || getenv("KC_DEBUG_ADDR"))
-      fprintf(stderr, "kc arena probe (%s): allocation %d, %.3f ms = %.2f TB/s, %p\n", what, i, best, rate[i], (void *)cand[i]);
-    if (rate[i] >= 4.8 || i == NCAND - 1) break;
+    return probe_bytes / (best * 1e-3) / 1e12;
+  };
+  const bool log = pe || getenv("KC_DEBUG_ADDR");
+  int rc = KC_OK;
+  for (int i = 0; i < NCAND && !rc; i++) {
+    rate[i] = probe(cand[i]);
+    if (rate[i] < 0) rc = KC_ERR_HIP;
+    if (log) fprintf(stderr, "kc arena probe (%s): allocation %d, %.2f TB/s, %p\n", what, i, rate[i], (void *)cand[i]);
+    if (rc || rate[i] >= 4.8) break;
+    // Second chance for the same allocation: written once from end to end, given back and asked for again, a slow
+    // arena comes back fast more often than not (three of four times; giving it back unwritten never helped).
+    if (hipMemsetAsync(cand[i], 0, bytes, c->stream) != hipSuccess || hipStreamSynchronize(c->stream) != hipSuccess) rc = KC_ERR_HIP;
+    if (!rc) {
+      (void)hipFree(cand[i]);
+      cand[i] = nullptr;
+      rate[i] = 0;
+      if (hipMalloc((void **)&cand[i], bytes) != hipSuccess) {
+        (void)hipGetLastError();
+        cand[i] = nullptr;
+        break;  // (cannot happen: the same size was just given back) -- the best of the others, if any
+      }
+      rate[i] = probe(cand[i]);
+      if (rate[i] < 0) rc = KC_ERR_HIP;
+      if (log) fprintf(stderr, "kc arena probe (%s): allocation %d written, freed and allocated again: %.2f TB/s, %p\n", what, i, rate[i], (void *)cand[i]);
+    }
+    if (rc || rate[i] >= 4.8 || i == NCAND - 1) break;
     size_t free_b = 0, total_b = 0;
     if (hipMemGetInfo(&free_b, &total_b) != hipSuccess || free_b < bytes + ((size_t)8 << 30)) break;  // no room to hold another
     if (hipMalloc((void **)&cand[i + 1], bytes) != hipSuccess) {
@@ -592,12 +614,17 @@ static int pick_fast_arena(kc_ctx *c, uint64_t **arena, size_t bytes, uint32_t G
     }
     ncand = i + 2;
   }
+  int best_i = -1;
   for (int i = 0; i < ncand; i++)
-    if (i != best_i && cand[i]) HIPCHK(hipFree(cand[i]));
-  *arena = cand[best_i];
+    if (cand[i] && (best_i < 0 || rate[i] > rate[best_i])) best_i = i;
+  for (int i = 0; i < ncand; i++)
+    if (i != best_i && cand[i]) (void)hipFree(cand[i]);
+  *arena = best_i >= 0 ? cand[best_i] : nullptr;
   (void)hipEventDestroy(e0);
   (void)hipEventDestroy(e1);
-  return KC_OK;
+  if (!rc && !*arena) rc = KC_ERR_OUT_OF_MEMORY;
+  if (rc) snprintf(g_last_error, sizeof(g_last_error), "choosing the %s arena failed", what);
+  return rc;
 }
 
 constexpr double KC_MAX_REGION_LOAD = 0.72;  // highest mean load of the region tables bk_init plans with

@@ -78,3 +78,12 @@ def test_cpp_driver_matches_oracle(tmp_path, mode):
     (keys, counts, left, right), st = O.count_reads(reads, quals, k=k)
     want = sorted("%s %d %s %s" % (O.kmer_to_string(keys[i], k), counts[i], chr(left[i]), chr(right[i])) for i in range(len(counts)))
     assert out.splitlines() == want and len(want) > 50
+
+
+def test_shard_bucket_ranges_tile_the_buckets(tmp_path):
+    """csrc/kc_shard.hpp's ownership arithmetic on the host (tests/cpp/test_shard_ranges.cpp): every bucket has exactly one
+    owner for every bucket and shard count, shard_of_bucket agrees with the ranges."""
+    exe = os.path.join(str(tmp_path), "test_shard_ranges")
+    subprocess.check_call([HIPCC, "-std=c++17", "-O1", "--offload-arch=gfx950", "-o", exe, os.path.join(ROOT, "tests", "cpp", "test_shard_ranges.cpp")])
+    out = subprocess.run([exe], capture_output=True, text=True)
+    assert out.returncode == 0 and out.stdout.strip().endswith("bad=0"), out.stdout + out.stderr

@@ -281,6 +281,16 @@ int kc_flush(kc_ctx *ctx);
 int kc_finalize(kc_ctx *ctx, kc_result *out);
 /* begin_iterate/get_next_entry in bulk: copy the results to host arrays sized from kc_result.n. */
 int kc_copy_results(kc_ctx *ctx, uint64_t *keys, uint16_t *counts, uint8_t *left, uint8_t *right);
+/* The same results in the shape HashTableGPUDriver hands them to its host (output_keys / output_vals,
+ * gpu_hash_table.cpp:776-784, gpu_hash_table.hpp:64-75): keys[n*num_longs] and one 8-byte kc_count_exts per entry
+ * (= kcount_gpu::CountExts: uint32 count, int8 left, int8 right), packed on the device and copied once, so that a
+ * driver's get_next_entry can point straight into the two arrays.  Either pointer may be NULL. */
+typedef struct kc_count_exts {
+  uint32_t count;
+  int8_t left, right;
+  int8_t pad[2];
+} kc_count_exts;
+int kc_copy_results_entries(kc_ctx *ctx, uint64_t *keys, kc_count_exts *vals);
 /* KmerDHT::kmer_exists / get_kmer_count / get_local_kmer_counts (src/kcount/kmer_dht.cpp:198-245) in bulk, against the
  * results kept in HBM: nq k-mers of num_longs words each, in either orientation; counts[i] = 0 (and left/right = 0)
  * when the k-mer did not survive.  The index over the results is built on the first call after kc_finalize.

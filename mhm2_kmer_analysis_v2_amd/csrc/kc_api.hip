@@ -2347,6 +2347,34 @@ extern "C" int kc_copy_results(kc_ctx *c, uint64_t *keys, uint16_t *counts, uint
   return KC_OK;
 }
 
+// count / left / right of every result packed into the 8 bytes of a kc_count_exts (kcount_gpu::CountExts)
+__global__ void kc_pack_count_exts_kernel(const uint16_t *counts, const uint8_t *left, const uint8_t *right, uint64_t n, uint64_t *vals) {
+  const uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i < n) vals[i] = (uint64_t)counts[i] | ((uint64_t)left[i] << 32) | ((uint64_t)right[i] << 40);
+}
+
+extern "C" int kc_copy_results_entries(kc_ctx *c, uint64_t *keys, kc_count_exts *vals) {
+  static_assert(sizeof(kc_count_exts) == 8, "kc_count_exts is one 8-byte word");
+  if (!c) return KC_ERR_INVALID_ARG;
+  if (!c->finalized) return KC_ERR_STATE;
+  HIPCHK(hipSetDevice(c->cfg.device));
+  const uint64_t n = c->out_n;
+  if (!n) return KC_OK;
+  if (keys) HIPCHK(hipMemcpy(keys, c->nl != c->nl_ext ? c->d_out_keys_ext : c->d_out_keys, n * c->nl_ext * 8, hipMemcpyDeviceToHost));
+  if (vals) {
+    uint64_t *d_vals = nullptr;
+    HIPCHK(hipMalloc((void **)&d_vals, n * 8));
+    hipLaunchKernelGGL(kc_pack_count_exts_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, c->stream, c->d_out_counts, c->d_out_left,
+                       c->d_out_right, n, d_vals);
+    hipError_t e = hipGetLastError();
+    if (e == hipSuccess) e = hipStreamSynchronize(c->stream);
+    if (e == hipSuccess) e = hipMemcpy(vals, d_vals, n * 8, hipMemcpyDeviceToHost);
+    (void)hipFree(d_vals);
+    if (e != hipSuccess) return hip_fail(e, "kc_copy_results_entries", __LINE__);
+  }
+  return KC_OK;
+}
+
 // entries of the LDS-counted regions, unfiltered: two passes (size, then write)
 static int bk_dump(kc_ctx *c, uint64_t **dk, uint16_t **dc, uint16_t **de, uint64_t *n_regions) {
   int rc = bk_build_regions(c);

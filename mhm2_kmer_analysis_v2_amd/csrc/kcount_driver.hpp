@@ -36,7 +36,11 @@
 
 namespace kcount_mi355 {
 
+// gpu_hash_table.hpp:54-57
+enum PASS_TYPE { READ_KMERS_PASS = 0, CTG_KMERS_PASS = 1 };
+
 using count_t = uint32_t;
+using ext_count_t = uint16_t;
 
 [[noreturn]] inline void die(const char *what, int status) {
   std::fprintf(stderr, "kcount_mi355: %s failed: %s (%d) %s\n", what, kc_error_string(status), status, kc_last_error());
@@ -51,11 +55,16 @@ struct CountExts {
   count_t count;
   int8_t left, right;
 };
+static_assert(sizeof(CountExts) == sizeof(kc_count_exts), "CountExts must have the layout of kc_count_exts");
 
 template <int MAX_K>
 struct KmerArray {
   static const int N_LONGS = (MAX_K + 31) / 32;
   uint64_t longs[N_LONGS];
+
+  void set(const uint64_t *x) {  // gpu_hash_table.hpp:74
+    for (int i = 0; i < N_LONGS; i++) longs[i] = x[i];
+  }
 };
 
 // gpu_hash_table.hpp:109-115
@@ -85,7 +94,6 @@ class ParseAndPackDriver {
   kc_ctx *ctx = nullptr;
   int rank_n;
   int kmer_len;
-  int num_longs;   // of a k-mer (the reference's N_LONGS)
   int rec_longs;   // of a record on the shard wire (kc_record_longs)
   bool records_mode;
   uint64_t *d_records = nullptr;  // rank_n segments of seg_capacity records
@@ -107,7 +115,7 @@ class ParseAndPackDriver {
   // supermers (the native flow; ownership is then a hash of the k-mer, F3 in SURVEY.md).
   ParseAndPackDriver(int upcxx_rank_me, int upcxx_rank_n, int qual_offset, int kmer_len, int num_kmer_longs, int minimizer_len,
                      double &init_time, bool records_mode = false, int device = 0)
-      : rank_n(upcxx_rank_n), kmer_len(kmer_len), num_longs(num_kmer_longs), rec_longs(kc_record_longs(kmer_len)),
+      : rank_n(upcxx_rank_n), kmer_len(kmer_len), rec_longs(kc_record_longs(kmer_len)),
         records_mode(records_mode), h_counts(upcxx_rank_n, 0) {
     StopWatch sw;
     kc_config cfg{};
@@ -220,10 +228,22 @@ class HashTableDriver {
  public:
   static constexpr size_t HASHTABLE_BLOCK_SIZE = 1u << 24;  // role of KCOUNT_GPU_HASHTABLE_BLOCK_SIZE, much larger
 
+  // gpu_hash_table.hpp:150: read by the host (kcount_gpu.cpp:315,330,376).  The contig pass is dead in the proxy
+  // (SURVEY.md F8): nothing here ever sets CTG_KMERS_PASS.
+  PASS_TYPE pass_type = READ_KMERS_PASS;
+
   HashTableDriver() = default;
   ~HashTableDriver() { kc_destroy(ctx); }
   HashTableDriver(const HashTableDriver &) = delete;
   HashTableDriver &operator=(const HashTableDriver &) = delete;
+  // the reference's host constructs its member from a temporary (kcount_gpu.cpp:218-219, `ht_gpu_driver({})`): the
+  // context moves with the driver
+  HashTableDriver(HashTableDriver &&o) noexcept
+      : ctx(o.ctx), kmer_len(o.kmer_len), elem_buff(std::move(o.elem_buff)), packed_buff(std::move(o.packed_buff)),
+        output_keys(std::move(o.output_keys)), output_vals(std::move(o.output_vals)), output_index(o.output_index), stats(o.stats),
+        num_gpu_calls(o.num_gpu_calls), final_capacity(o.final_capacity), t_insert(o.t_insert), pass_type(o.pass_type) {
+    o.ctx = nullptr;
+  }
 
   // gpu_hash_table.hpp:155-156.  use_qf is accepted and ignored (the filter is forced off in the reference too,
   // kcount_gpu.cpp:227-232).  Sizing problems come back through `warnings` like the reference's do
@@ -274,10 +294,17 @@ class HashTableDriver {
 
   // gpu_hash_table.cpp:681-695: one 4-bit packed supermer as kcount_gpu.cpp:153-161 cuts it (odd nibbles masked to 0);
   // the bytes are joined by '_' exactly like the reference's elem_buff_host and unpacked on the device
-  void insert_supermer(const std::string &packed, count_t /*supermer_count*/) {
-    if (packed_buff.size() + packed.size() + 1 >= HASHTABLE_BLOCK_SIZE) flush_block();
-    packed_buff += packed;
-    packed_buff += '_';
+  // supermer_count: every k-mer of the supermer is seen that many times (insert_supermer_from_read adds `count` to the
+  // k-mer and to its extensions, kcount_cpu.cpp:349-353).  Reads always come with 1 (kcount.cpp:87 passes depth 0,
+  // kcount_gpu.cpp:160 turns it into 1); a larger count is submitted as that many copies, which saturate exactly like
+  // the reference's min(count + n, 65535) chain does.
+  void insert_supermer(const std::string &packed, count_t supermer_count) {
+    const count_t copies = supermer_count ? supermer_count : 1;
+    for (count_t c = 0; c < copies; c++) {
+      if (packed_buff.size() + packed.size() + 1 >= HASHTABLE_BLOCK_SIZE) flush_block();
+      packed_buff += packed;
+      packed_buff += '_';
+    }
     stats.attempted++;
   }
   // the CPU backend's wire format (kcount_cpu.cpp:477-493): ASCII, case = quality.  '_' bytes only separate.
@@ -312,16 +339,13 @@ class HashTableDriver {
     num_purged = st.num_purged;
     stats.new_inserts = st.num_unique;
     final_capacity = r.n;
-    std::vector<uint64_t> keys(r.n * N_LONGS);
-    std::vector<uint16_t> counts(r.n);
-    std::vector<uint8_t> left(r.n), right(r.n);
-    check(kc_copy_results(ctx, keys.data(), counts.data(), left.data(), right.data()), "kc_copy_results");
+    // the two arrays get_next_entry points into are filled by one device-to-host copy each: a KmerArray is its N_LONGS
+    // words, a CountExts is packed on the device (kc_copy_results_entries)
+    static_assert(sizeof(KmerArray<MAX_K>) == N_LONGS * 8, "KmerArray is its words");
     output_keys.resize(r.n);
     output_vals.resize(r.n);
-    for (uint64_t i = 0; i < r.n; i++) {
-      for (int j = 0; j < N_LONGS; j++) output_keys[i].longs[j] = keys[i * N_LONGS + j];
-      output_vals[i] = {counts[i], (int8_t)left[i], (int8_t)right[i]};
-    }
+    check(kc_copy_results_entries(ctx, reinterpret_cast<uint64_t *>(output_keys.data()), reinterpret_cast<kc_count_exts *>(output_vals.data())),
+          "kc_copy_results_entries");
   }
   void begin_iterate() { output_index = 0; }
   // {nullptr, nullptr} at the end; unlike the reference no empty slots are returned (count is never 0)

@@ -80,6 +80,56 @@ def test_cpp_driver_matches_oracle(tmp_path, mode):
     assert out.splitlines() == want and len(want) > 50
 
 
+SURFACE = os.path.join(ROOT, "tests", "cpp", "test_surface.cpp")
+REFERENCE = "/root/reference/src"
+
+
+def build_surface(tmp):
+    exe = os.path.join(str(tmp), "test_surface")
+    subprocess.check_call([HIPCC, "-std=c++17", "-O1", "-Wall", "-Werror", "-o", exe, SURFACE, "-L" + CSRC, "-lkcount_mi355", "-Wl,-rpath," + CSRC])
+    return exe
+
+
+def test_driver_surface_compiles_against_the_adapter(tmp_path):
+    """tests/cpp/test_surface.cpp: every driver expression src/kcount/kcount_gpu.cpp uses (pass_type / PASS_TYPE, the
+    member built from `{}`, get_stats().dropped, get_qf_load_factor, done_ctg_kmer_inserts, ...), inside namespace
+    kcount_gpu with INTEGRATION.md's alias block, compiles and links against kcount_driver.hpp"""
+    assert os.path.exists(build_surface(tmp_path))
+
+
+@pytest.mark.skipif(not os.path.isdir(REFERENCE), reason="the reference checkout is not on this machine")
+def test_driver_surface_is_valid_against_the_reference_headers():
+    """the same text, unmodified, against the reference's own parse_and_pack.hpp / gpu_hash_table.hpp (syntax only: the
+    reference's device library cannot be built here): what the adapter accepts is what the reference's host file writes"""
+    subprocess.check_call(["g++", "-std=c++17", "-fsyntax-only", "-DSURFACE_REFERENCE", "-I" + REFERENCE, "-I" + os.path.join(REFERENCE, "kcount"), SURFACE])
+
+
+def test_integration_md_alias_block_is_the_one_the_surface_test_compiles():
+    """INTEGRATION.md's edit and the alias block of tests/cpp/test_surface.cpp are the same lines"""
+    text = open(SURFACE).read()
+    block = text.split("// ---- the edit INTEGRATION.md prescribes for src/kcount/kcount_gpu.cpp, verbatim ----")[1].split("// ---- end of the edit ----")[0]
+    doc = open(os.path.join(ROOT, "INTEGRATION.md")).read()
+    for line in block.strip().splitlines():
+        line = line.strip()
+        if line.startswith("#include"):
+            continue
+        assert line in doc, "INTEGRATION.md lacks: " + line
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("k", [21, 51, 77])
+def test_driver_surface_runs_like_kcount_gpu_cpp(tmp_path, k):
+    """the surface program run once: three target ranks, the reference's own sequence of calls, result = the oracle's"""
+    exe = build_surface(tmp_path)
+    rng = np.random.default_rng(79 + k)
+    reads, quals = random_reads(rng, 500, min_len=25, max_len=160, genome_len=1800)
+    masked = ["".join(c.lower() if ord(x) < 33 + 20 else c for c, x in zip(r, q)) for r, q in zip(reads, quals)]
+    out = subprocess.run([exe, str(k)], input="\n".join(masked) + "\n", capture_output=True, text=True, check=True).stdout
+    (keys, counts, left, right), st = O.count_reads(reads, quals, k=k)
+    want = sorted("%s %d %s %s" % (O.kmer_to_string(keys[i], k), counts[i], chr(left[i]), chr(right[i])) for i in range(len(counts)))
+    assert out.splitlines() == want and len(want) > 50
+
+
 def test_shard_bucket_ranges_tile_the_buckets(tmp_path):
     """csrc/kc_shard.hpp's ownership arithmetic on the host (tests/cpp/test_shard_ranges.cpp): every bucket has exactly one
     owner for every bucket and shard count, shard_of_bucket agrees with the ranges."""

@@ -2206,14 +2206,15 @@ static int bk_finalize(kc_ctx *c) {
   // blocks of up to 8192 entries, smaller when few results are expected (all the tails together stay within a
   // quarter of the estimate)
   uint32_t block = 0;
-  if (max_wg < PLAN_RUNS) {
+  if (2 * max_wg <= PLAN_RUNS) {  // (a workgroup may leave two holes: its current block's tail and an unused spare)
     block = 64;
     while (block < 8192u && (uint64_t)block * 2 * max_wg * 4 <= cap) block *= 2;
   }
   if (block && !c->d_out_plan) {
-    HIPCHK(hipMalloc((void **)&c->d_out_plan, (PLAN_WORDS + 2 * (size_t)max_wg) * 8));
+    HIPCHK(hipMalloc((void **)&c->d_out_plan, (PLAN_WORDS + 4 * (size_t)max_wg) * 8));
   }
-  const uint64_t slack = (uint64_t)block * max_wg;
+  // a workgroup holds at most two blocks that are not full, each a multiple of `block` that covers a region table
+  const uint64_t slack = block ? 2 * (((uint64_t)c->gm.S + block - 1) / block * block) * max_wg : 0;
   cap += slack;
   for (int attempt = 0; attempt < 3; attempt++) {
     rc = alloc_results(c, cap);
@@ -2230,11 +2231,11 @@ static int bk_finalize(kc_ctx *c) {
     ob.cursor = c->d_ctrs + CTR_OUT;
     ob.block = block;
     ob.tails = block ? c->d_out_plan + PLAN_WORDS : nullptr;
-    if (block) HIPCHK(hipMemsetAsync(ob.tails, 0, 2 * (size_t)max_wg * 8, c->stream));
+    if (block) HIPCHK(hipMemsetAsync(ob.tails, 0, 4 * (size_t)max_wg * 8, c->stream));
     rc = bk_count(c, ob, false);
     if (rc) return rc;
     if (block) {
-      hipLaunchKernelGGL(kc_out_plan_kernel, dim3(1), dim3(WGB), 0, c->stream, ob.tails, max_wg, ob.cursor, c->d_cb + CB_OUT_RESERVED,
+      hipLaunchKernelGGL(kc_out_plan_kernel, dim3(1), dim3(WGB), 0, c->stream, ob.tails, 2 * max_wg, ob.cursor, c->d_cb + CB_OUT_RESERVED,
                          c->d_out_plan);
       const unsigned mgrid = (unsigned)std::min<uint64_t>((slack + 255) / 256, 4096);
       switch (c->nl) {
@@ -2250,9 +2251,8 @@ static int bk_finalize(kc_ctx *c) {
     if (rc) return rc;
 #ifdef KC_STAMPS
     (void)sync_cb(c);
-    fprintf(stderr, "count kernel cycles (thread 0, summed over workgroups): zero %llu insert %llu satscan %llu vote %llu write %llu\n",
-            (unsigned long long)c->h_cb[8], (unsigned long long)c->h_cb[9], (unsigned long long)c->h_cb[10],
-            (unsigned long long)c->h_cb[11], (unsigned long long)c->h_cb[12]);
+    fprintf(stderr, "count kernel cycles (thread 0, summed over workgroups): header %llu insert %llu table pass %llu\n",
+            (unsigned long long)c->h_cb[8], (unsigned long long)c->h_cb[9], (unsigned long long)c->h_cb[10]);
 #endif
     if (block) {
       rc = sync_cb(c);

@@ -1084,27 +1084,25 @@ constexpr uint32_t CHAIN_LDS = 512;  // longest region chain (L2MAX) the count k
 template <int NL>
 struct CountLDS {  // header at the start of the dynamic LDS; the arrays follow, strided by the region's S
   static constexpr uint32_t SMAX = NL <= 2 ? 4096 : 2048;
-  static constexpr int EW = NL == 1 ? 6 : 5;  // extension words per slot; the last one takes the vote's result
-  uint32_t chain[CHAIN_LDS];  // the region's chunk ids
-  uint32_t nout, nocc, fail, gbase_lo, gbase_hi;
-  uint32_t gbase2_lo, gbase2_hi, split;  // ranks >= split continue at gbase2 (a region may straddle two blocks)
-  unsigned long long sum;
+  static constexpr int EW = NL == 1 ? 6 : 5;  // extension words per slot
+  // the region's chunk ids; two buffers: the next region's ids are fetched while this one is counted
+  uint32_t chain[2][CHAIN_LDS];
+  uint32_t hdr[2][2];  // ... and its length and flag
+  uint32_t nout;       // survivors of the region so far (their ranks)
+  uint32_t fail[2];    // the region does not fit the table (alternating with the chain buffers)
+  uint32_t gbase_lo, gbase_hi, gbase2_lo, gbase2_hi, split;  // ranks < split sit at gbase + rank, the others at gbase2 + (rank - split)
   static constexpr size_t header_bytes() { return (sizeof(CountLDS<NL>) + 15) & ~size_t(15); }
   // cp: compact records, 32-bit keys
-  static constexpr size_t bytes(uint32_t S, bool cp) { return header_bytes() + (size_t)S * ((cp ? 4 : 8 * NL) + 4 * EW + 2) + 16; }
+  static constexpr size_t bytes(uint32_t S, bool cp) { return header_bytes() + (size_t)S * ((cp ? 4 : 8 * NL) + 4 * EW) + 16; }
 };
 
 // the arrays of one region table: word w of slot s at keys[w*S + s] (the LAST word is the claim word; compact
 // records: one 32-bit key per slot);
 // ext[q*S + s], five words (EW = 5): q = 0 left A|C<<16, 1 left G|T<<16, 2 right A|C<<16, 3 right G|T<<16,
 // 4 left none | right none<<16; six words: q = 0 left A|C<<16, 1 left G|T<<16, 2 left none, 3-5 the same of the right
-// (after the vote an entry's last word holds its count, extensions and rank for the write-out)
-// occ lists the occupied slots in claim order, so that the vote, the write-out and the clean-up of a region visit
-// only its entries (dense lanes) instead of scanning every slot
 struct CountTab {
   uint64_t *keys;
   uint32_t *ext;
-  uint16_t *occ;
   uint32_t S, lgS;
 };
 
@@ -1115,7 +1113,6 @@ __device__ __forceinline__ CountTab count_tab(uint8_t *smem, uint32_t S) {
   t.keys = reinterpret_cast<uint64_t *>(p);
   p += (size_t)S * (CP ? 4 : 8 * NL);
   t.ext = reinterpret_cast<uint32_t *>(p);
-  t.occ = reinterpret_cast<uint16_t *>(t.ext + CountLDS<NL>::EW * (size_t)S);
   t.S = S;
   t.lgS = 31u - (uint32_t)__clz(S);
   return t;
@@ -1151,23 +1148,14 @@ struct OutBufs {
   uint64_t *cursor;  // global append position (results: &ctrs[CTR_OUT])
   // block > 0: a workgroup takes its output positions from private blocks of `block` entries and bumps the cursor
   // only when a block is used up (a bump per region makes every workgroup of the chip queue on one address: measured
-  // 16 of the count kernel's 42 ms).  Each workgroup leaves the unused tail of its last block in tails[2*wg], and
-  // kc_out_plan_kernel / kc_out_move_kernel then close those holes with entries from the end of the arrays.
+  // 16 of the count kernel's 42 ms).  A region's survivors are ranked while they are written (one pass over the table,
+  // no count-then-reserve), so before each region the workgroup makes sure it holds room for as many as the region can
+  // have at most: its current block and, when that has less left, a spare one.  Each workgroup leaves the unused tails
+  // of the (at most two) blocks it holds at the end in tails[4*wg .. 4*wg+3], and kc_out_plan_kernel /
+  // kc_out_move_kernel then close those holes with entries from the end of the arrays.
   uint32_t block;
-  uint64_t *tails;   // [2 * workgroups]: start and length of the hole
+  uint64_t *tails;   // [2 * 2 * workgroups]: start and length of every hole
 };
-
-// append the slots that lanes have just claimed to the region's list: one LDS atomic per wave
-__device__ __forceinline__ void occ_push(uint32_t *nocc, uint16_t *occ, bool is_new, uint32_t slot) {
-  const uint64_t m = __ballot(is_new);
-  if (m) {
-    const int leader = __ffsll((long long)m) - 1;
-    uint32_t base = 0;
-    if ((int)lane_id() == leader) base = atomicAdd(nocc, (uint32_t)__popcll(m));
-    base = __shfl(base, leader);
-    if (is_new) occ[base + (uint32_t)__popcll(m & ((1ULL << lane_id()) - 1ULL))] = (uint16_t)slot;
-  }
-}
 
 // One-word keys: the probe written for a low instruction count.  The region kernels are bound by instruction
 // issue (PMC: as many scalar as vector instructions, almost no idle LDS or HBM), and the lanes of a wave probe in
@@ -1267,6 +1255,15 @@ __device__ __forceinline__ uint32_t lds_probeN(const CountTab &tb, const uint64_
 // __launch_bounds__(WGB, 8): two 1024-thread workgroups per CU need at most 64 registers per lane.
 // CP: compact 32-bit records (cp_pack32); the table keys are their upper 26 bits, the k-mer is rebuilt from the
 // region and the key when an entry is written out.
+//
+// A region costs the workgroup two barriers: [inserts] barrier [one pass over the table: vote, purge, rank, write out,
+// clean the slot] barrier.  Everything a region needs from memory before its first record -- its length, its flag, its
+// chunk ids -- is fetched one region ahead (registers, then the other half of T.chain), and one word of every 128-byte
+// line of the next region's records is touched before the table pass, so that the record loads after the barrier
+// find their lines in the L2 instead of waiting for HBM with nothing else to do.  (Round 2 listed the occupied slots,
+// voted over the list, reserved the output in a third step and wrote in a fourth: seven barriers, 40 % of the kernel's
+// time in those short dependent phases.)
+constexpr uint32_t CHAIN_PRE = 64;  // chunk ids fetched ahead (a region of up to 65535 records has at most 64 chunks of 1024)
 template <int NL, bool DUMP, bool CP>
 __global__ __launch_bounds__(WGB, 8) void kc_count_kernel(Geom gm, BucketBufs bb, OutBufs out, int dmin_thres, uint64_t *ctrs,
                                                        uint64_t *cb) {
@@ -1280,7 +1277,7 @@ __global__ __launch_bounds__(WGB, 8) void kc_count_kernel(Geom gm, BucketBufs bb
   // diagnostic builds only (-DKC_STAMPS): thread 0 accumulates the cycles between the phase boundaries of every region
   // into cb[8..]; the shipped build has no stamp code at all
 #ifdef KC_STAMPS
-  unsigned long long tacc[6] = {0, 0, 0, 0, 0, 0}, tprev = 0;
+  unsigned long long tacc[6] = {0, 0, 0, 0, 0, 0}, tprev = __builtin_amdgcn_s_memtime();
   const bool stamp = tid == 0;
 #define KC_STAMP(k)                                             \
   if (stamp) {                                                  \
@@ -1304,242 +1301,279 @@ __global__ __launch_bounds__(WGB, 8) void kc_count_kernel(Geom gm, BucketBufs bb
     for (int e = 0; e < EW; e++) tb.ext[e * SM + s] = 0;
   };
   for (uint32_t s = tid; s < S; s += WGB) reset_slot(s);
-  if (tid == 0) T.nocc = 0;
+  if (tid == 0) {
+    T.nout = 0;
+    T.fail[0] = T.fail[1] = 0;
+  }
+  // thread 0: the output blocks this workgroup holds -- the one it is filling and a spare
+  uint64_t cur_base = 0, cur_left = 0, sp_base = 0, sp_left = 0;
+  bool pending = false;  // thread 0: the last counted region's survivors are not yet taken off the blocks
+  auto settle = [&]() {  // thread 0, after the barrier that ends a region's table pass
+    if (!pending) return;
+    pending = false;
+    uint64_t need = T.nout;
+    T.nout = 0;
+    if (need <= cur_left) {
+      cur_base += need;
+      cur_left -= need;
+    } else {  // the current block is used up: the spare becomes the current one
+      need -= cur_left;
+      cur_base = sp_base + need;
+      cur_left = sp_left - need;
+      sp_base = sp_left = 0;
+    }
+  };
+  // every lane's share of the statistics (flushed once, at the end)
+  uint32_t acc_entries = 0, acc_kept = 0;
+  unsigned long long acc_sum = 0;
+  uint32_t sink = 0;  // what the look-ahead touches end up in (never zero-tested before the end)
+  // ---- look-ahead state: region r's header is in registers / T.chain[buf] when its iteration starts ----
+  // (vector loads by a few lanes, parked in LDS: a scalar load's wait would also be a wait for every LDS operation in
+  // flight, and the first one of the insert loop would then sit out the scalar load's latency)
+  size_t r = blockIdx.x;
+  int buf = 0;
+  const uint32_t npre = min(CHAIN_PRE, gm.L2MAX);
+  auto header_word = [&](size_t reg) -> uint32_t {  // lane t < npre: chunk id t; lane npre: the length; lane npre + 1: the flag
+    const uint32_t *src = (uint32_t)tid < npre ? bb.chain2 + reg * gm.L2MAX + tid : (uint32_t)tid == npre ? bb.cnt2 + reg : bb.flag + reg;
+    return *src;
+  };
+  auto header_park = [&](int b, uint32_t v) {
+    if ((uint32_t)tid < npre) T.chain[b][tid] = v;
+    else T.hdr[b][tid - npre] = v;
+  };
+  if (r < R && (uint32_t)tid < npre + 2u) header_park(0, header_word(r));
   __syncthreads();
-  // thread 0: this workgroup's output block and its share of the statistics (flushed once, at the end)
-  uint64_t blk_base = 0, blk_left = 0, acc_entries = 0, acc_purged = 0, acc_sum = 0;
-  for (size_t r = blockIdx.x; r < R; r += gridDim.x) {
-    const uint32_t n = bb.cnt2[r];
-    if (n == 0 || bb.flag[r]) continue;  // uniform across the workgroup
-    if (n > KC_COUNT_MAX) {              // a 16-bit counter could overflow: the global table takes the region
-      if (tid == 0) bb.flag[r] = 2;
-      continue;
-    }
-#ifdef KC_STAMPS
-    if (stamp) tprev = __builtin_amdgcn_s_memtime();
-#endif
-    if (tid == 0) {
-      T.nout = 0;
-      T.fail = 0;
-      T.sum = 0;
-    }
-    {
-      const uint32_t nch = (n + (1u << gm.log2CH2) - 1) >> gm.log2CH2;
-      if ((uint32_t)tid < nch) T.chain[tid] = bb.chain2[r * gm.L2MAX + tid];
-    }
-    __syncthreads();
-    KC_STAMP(0)  // chain
-    // several independent loads in flight per thread before the dependent LDS work starts
+  const uint32_t CHm = (1u << gm.log2CH2) - 1u;
+  while (r < R) {
+    const size_t rn = r + gridDim.x;
+    const bool has_next = rn < R;
+    // the next region's header: requested now, parked before this iteration's barrier
+    uint32_t c_nxt = 0;
+    if (has_next && (uint32_t)tid < npre + 2u) c_nxt = header_word(rn);
+    const uint32_t n = T.hdr[buf][0], f_cur = T.hdr[buf][1];
+    const bool process = n != 0 && f_cur == 0 && n <= KC_COUNT_MAX;  // uniform across the workgroup
+    if (n > KC_COUNT_MAX && f_cur == 0 && tid == 0) bb.flag[r] = 2;  // a 16-bit counter could overflow: the global table takes the region
+    if (process) {
+      if (tid == 0) {
+        settle();
+        // room for as many survivors as this region can have: count >= 2 each, and no more than slots
+        const uint64_t most = DUMP ? min(n, S) : min(n >> 1, S);
+        if (out.block != 0) {
+          if (cur_left + sp_left < most) {  // (then there is no spare: a spare, S entries or more and untouched, always suffices)
+            const uint64_t take = ((uint64_t)S + out.block - 1) / out.block * out.block;
+            sp_base = atomicAdd((unsigned long long *)out.cursor, (unsigned long long)take);
+            sp_left = take;
+          }
+          T.gbase_lo = (uint32_t)cur_base;
+          T.gbase_hi = (uint32_t)(cur_base >> 32);
+          T.gbase2_lo = (uint32_t)sp_base;
+          T.gbase2_hi = (uint32_t)(sp_base >> 32);
+          T.split = (uint32_t)min(cur_left, (uint64_t)0xFFFFFFFFu);
+        }
+        pending = true;
+      }
+      const uint32_t nch = (n + CHm) >> gm.log2CH2;
+      if (nch > npre) {  // (chunks far smaller than a region: tiny geometries only)
+        for (uint32_t i = npre + tid; i < nch; i += WGB) T.chain[buf][i] = bb.chain2[r * gm.L2MAX + i];
+        __syncthreads();
+      }
+      KC_STAMP(0)  // header
+      // several independent loads in flight per thread before the dependent LDS work starts
 #ifndef KC_BATCH
 #define KC_BATCH 8
 #endif
-    constexpr int BATCH = NL == 1 ? KC_BATCH : NL == 2 ? 4 : 2;
-    const uint32_t CHm = (1u << gm.log2CH2) - 1u;
-    for (uint32_t i0 = 0; i0 < n; i0 += WGB * BATCH) {
-      uint64_t rec[BATCH][NL];
-      uint32_t rec32[BATCH];
-      // no branches around the loads (an out-of-range lane re-reads record 0): the compiler can then issue
-      // all of them before the first wait instead of fencing each one off in its own basic block
-      size_t at[BATCH];
+      constexpr int BATCH = NL == 1 ? KC_BATCH : NL == 2 ? 4 : 2;
+      for (uint32_t i0 = 0; i0 < n; i0 += WGB * BATCH) {
+        uint64_t rec[BATCH][NL];
+        uint32_t rec32[BATCH];
+        // no branches around the loads (an out-of-range lane re-reads record 0): the compiler can then issue
+        // all of them before the first wait instead of fencing each one off in its own basic block
+        size_t at[BATCH];
 #pragma unroll
-      for (int j = 0; j < BATCH; j++) {
-        uint32_t i = i0 + (uint32_t)j * WGB + tid;
-        i = i < n ? i : 0u;
-        at[j] = ((size_t)T.chain[i >> gm.log2CH2] << gm.log2CH2) + (i & CHm);
-      }
+        for (int j = 0; j < BATCH; j++) {
+          uint32_t i = i0 + (uint32_t)j * WGB + tid;
+          i = i < n ? i : 0u;
+          at[j] = ((size_t)T.chain[buf][i >> gm.log2CH2] << gm.log2CH2) + (i & CHm);
+        }
 #pragma unroll
-      for (int j = 0; j < BATCH; j++) {
-        if (CP) {
-          rec32[j] = reinterpret_cast<const uint32_t *>(bb.rec2)[at[j]];
+        for (int j = 0; j < BATCH; j++) {
+          if (CP) {
+            rec32[j] = reinterpret_cast<const uint32_t *>(bb.rec2)[at[j]];
+          } else {
+#pragma unroll
+            for (int w = 0; w < NL; w++) rec[j][w] = bb.rec2[at[j] * NL + w];
+          }
+        }
+        if constexpr (NL == 1 && CP) {
+          uint32_t failed = 0;
+#pragma unroll
+          for (int j = 0; j < BATCH; j++) {
+            const uint32_t v = (i0 + (uint32_t)j * WGB + tid) < n ? 1u : 0u;
+            const uint32_t r0 = rec32[j], key = r0 >> 6;
+            if (!__any(v)) continue;  // past the end of the region for the whole wave
+            const uint32_t s = lds_probe32(keys32, S - 1u, key, key & (S - 1u), ((key >> tb.lgS) << 1) | 1u, v, failed);
+            const uint32_t le = r0 & 7u, re = (r0 >> 3) & 7u;
+            // only lanes that hold a record touch the counters: the idle lanes of a wave all re-read record 0, and 64
+            // atomic adds of zero to one LDS word are serialised
+            if (v) ext_count<EW>(tb, s, le, re);
+          }
+          if (failed) T.fail[buf] = 1;
+        } else if constexpr (NL == 1) {
+          uint32_t failed = 0;
+#pragma unroll
+          for (int j = 0; j < BATCH; j++) {
+            const uint32_t v = (i0 + (uint32_t)j * WGB + tid) < n ? 1u : 0u;
+            const uint64_t r0 = rec[j][0], key = r0 & ~KC_EXT_MASK;
+            uint64_t kk[1] = {key};
+            if (!__any(v)) continue;  // past the end of the region for the whole wave
+            const uint32_t s = lds_probe1((unsigned long long *)tb.keys, S - 1u, key, hash_slot(kc_hash<1>(kk), S), v, failed);
+            // S5/S6: the k-mer itself, and each extension that is an ACGT base (codes 0-3; 4 = none adds 0).  Only
+            // lanes that hold a record touch the counters (see the compact path above)
+            const uint32_t le = (uint32_t)r0 & 7u, re = ((uint32_t)r0 >> 3) & 7u;
+            if (v) ext_count<EW>(tb, s, le, re);
+          }
+          if (failed) T.fail[buf] = 1;
         } else {
+          uint32_t failed = 0;
 #pragma unroll
-          for (int w = 0; w < NL; w++) rec[j][w] = bb.rec2[at[j] * NL + w];
+          for (int j = 0; j < BATCH; j++) {
+            const uint32_t v = (i0 + (uint32_t)j * WGB + tid) < n ? 1u : 0u;
+            if (!__any(v)) continue;  // past the end of the region for the whole wave
+            uint64_t key[NL];
+#pragma unroll
+            for (int w = 0; w < NL; w++) key[w] = rec[j][w];
+            const uint32_t le = (uint32_t)(rec[j][NL - 1] & 7u), re = (uint32_t)((rec[j][NL - 1] >> 3) & 7u);
+            key[NL - 1] &= ~KC_EXT_MASK;
+            const uint32_t s = lds_probeN<NL>(tb, key, hash_slot(kc_hash<NL>(key), S), v, failed);
+            if (v && !(failed & 1u)) ext_count<EW>(tb, s, le, re);
+          }
+          if (failed) T.fail[buf] = 1;
         }
-      }
-      if constexpr (NL == 1 && CP) {
-        uint32_t failed = 0;
-#pragma unroll
-        for (int j = 0; j < BATCH; j++) {
-          const uint32_t v = (i0 + (uint32_t)j * WGB + tid) < n ? 1u : 0u;
-          const uint32_t r0 = rec32[j], key = r0 >> 6;
-          if (!__any(v)) continue;  // past the end of the region for the whole wave
-          const uint32_t s = lds_probe32(keys32, S - 1u, key, key & (S - 1u), ((key >> tb.lgS) << 1) | 1u, v, failed);
-          const uint32_t le = r0 & 7u, re = (r0 >> 3) & 7u;
-          // only lanes that hold a record touch the counters: the idle lanes of a wave all re-read record 0, and 64
-          // atomic adds of zero to one LDS word are serialised
-          if (v) ext_count<EW>(tb, s, le, re);
-        }
-        if (failed) T.fail = 1;
-      } else if constexpr (NL == 1) {
-        uint32_t failed = 0;
-#pragma unroll
-        for (int j = 0; j < BATCH; j++) {
-          const uint32_t v = (i0 + (uint32_t)j * WGB + tid) < n ? 1u : 0u;
-          const uint64_t r0 = rec[j][0], key = r0 & ~KC_EXT_MASK;
-          uint64_t kk[1] = {key};
-          if (!__any(v)) continue;  // past the end of the region for the whole wave
-          const uint32_t s = lds_probe1((unsigned long long *)tb.keys, S - 1u, key, hash_slot(kc_hash<1>(kk), S), v, failed);
-          // S5/S6: the k-mer itself, and each extension that is an ACGT base (codes 0-3; 4 = none adds 0).  Only
-          // lanes that hold a record touch the counters (see the compact path above)
-          const uint32_t le = (uint32_t)r0 & 7u, re = ((uint32_t)r0 >> 3) & 7u;
-          if (v) ext_count<EW>(tb, s, le, re);
-        }
-        if (failed) T.fail = 1;
-      } else {
-        uint32_t failed = 0;
-#pragma unroll
-        for (int j = 0; j < BATCH; j++) {
-          const uint32_t v = (i0 + (uint32_t)j * WGB + tid) < n ? 1u : 0u;
-          if (!__any(v)) continue;  // past the end of the region for the whole wave
-          uint64_t key[NL];
-#pragma unroll
-          for (int w = 0; w < NL; w++) key[w] = rec[j][w];
-          const uint32_t le = (uint32_t)(rec[j][NL - 1] & 7u), re = (uint32_t)((rec[j][NL - 1] >> 3) & 7u);
-          key[NL - 1] &= ~KC_EXT_MASK;
-          const uint32_t s = lds_probeN<NL>(tb, key, hash_slot(kc_hash<NL>(key), S), v, failed);
-          if (v && !(failed & 1u)) ext_count<EW>(tb, s, le, re);
-        }
-        if (failed) T.fail = 1;
       }
     }
+    // the next region's header moves to the other half of T.chain / T.hdr (nobody reads that half before the barrier)
+    if (has_next && (uint32_t)tid < npre + 2u) header_park(buf ^ 1, c_nxt);
     __syncthreads();
     KC_STAMP(1)  // loads + inserts + barrier
-    // list the occupied slots (one pass over the table, one LDS atomic per wave): the vote, the write-out and the
-    // clean-up then visit only the region's entries, with every lane busy
-    for (uint32_t s0 = 0; s0 < S; s0 += WGB) {
-      const uint32_t s = s0 + tid;
-      bool taken = false;
-      if (s < S) taken = CP ? keys32[s] != 0xFFFFFFFFu : tb.keys[(NL - 1) * SM + s] != KEY_EMPTY;
-      occ_push(&T.nocc, tb.occ, taken, s);
-    }
-    __syncthreads();
-    KC_STAMP(2)  // list the entries
-    const uint32_t nocc = T.nocc;
-    // S7 vote + S8 purge over the region's entries; survivors get a rank.  A k-mer seen more than 65535 times may
-    // have overflowed a packed 16-bit extension counter: the region then goes to the global table instead.
-    // (every lane walks the loop: the survivors of a wave take their ranks from ONE add to the region's counter, and
-    // their counts are summed in the wave first -- a thousand single adds to one LDS word would be serialised)
-    for (uint32_t e0 = 0; e0 < nocc; e0 += WGB) {
-      const uint32_t e = e0 + tid;
-      const bool live = e < nocc;
-      const uint32_t s = live ? tb.occ[e] : 0u;
-      uint32_t w[EW];
-#pragma unroll
-      for (int x = 0; x < EW; x++) w[x] = live ? tb.ext[x * SM + s] : 0u;
-      // the k-mer's count: every occurrence bumped exactly one of the left side's five counters (<= 65535: n is)
-      const uint32_t count = (w[0] & 0xFFFFu) + (w[0] >> 16) + (w[1] & 0xFFFFu) + (w[1] >> 16) + (w[EW == 6 ? 2 : 4] & 0xFFFFu);
-      bool keep = false;
-      uint32_t l = 0, rr = 0;
-      if (DUMP) {
-        keep = live;
-      } else if (count >= 2) {
-        const uint32_t lc[4] = {w[0] & 0xFFFFu, w[0] >> 16, w[1] & 0xFFFFu, w[1] >> 16};
-        constexpr int R0 = EW == 6 ? 3 : 2;
-        const uint32_t rc[4] = {w[R0] & 0xFFFFu, w[R0] >> 16, w[R0 + 1] & 0xFFFFu, w[R0 + 1] >> 16};
-        l = vote_ext(lc, count, dmin_thres);
-        rr = vote_ext(rc, count, dmin_thres);
-        keep = l < 4u && rr < 4u;
-      }
-      const uint64_t m = __ballot(keep);
-      uint32_t wsum = keep ? count : 0u;  // < 2^16 each
-      for (int o = 32; o > 0; o >>= 1) wsum += __shfl_down(wsum, o);
-      if (m) {  // wave-uniform
-        const int leader = __ffsll((long long)m) - 1;
-        uint32_t base = 0;
-        if ((int)lane_id() == leader) base = atomicAdd(&T.nout, (uint32_t)__popcll(m));
-        base = __shfl(base, leader);
-        if (lane_id() == 0 && !DUMP) atomicAdd(&T.sum, (unsigned long long)wsum);
-        if (keep) {
-          const uint32_t rank = base + (uint32_t)__popcll(m & ((1ULL << lane_id()) - 1ULL));
-          tb.ext[(EW - 1) * SM + s] = DUMP ? (count | (rank << 20)) : ((count & 0xFFFFu) | (l << 16) | (rr << 18) | (rank << 20));
+    if (process) {
+      // touch the next region's records, one word per 128-byte line, so that its loads after the next barrier hit the L2
+      uint32_t touch = 0;
+      if (has_next) {
+        const uint32_t n_nxt = T.hdr[buf ^ 1][0], f_nxt = T.hdr[buf ^ 1][1];
+        constexpr uint32_t PER_LINE = CP ? 32u : 16u / NL;  // records per 128 bytes
+        const uint32_t i = (uint32_t)tid * PER_LINE;
+        if (f_nxt == 0 && n_nxt <= KC_COUNT_MAX && i < n_nxt && (i >> gm.log2CH2) < npre) {
+          const size_t a = ((size_t)T.chain[buf ^ 1][i >> gm.log2CH2] << gm.log2CH2) + (i & CHm);
+          touch = CP ? reinterpret_cast<const uint32_t *>(bb.rec2)[a] : (uint32_t)bb.rec2[a * NL];
         }
       }
-      if (live && !keep) tb.ext[(EW - 1) * SM + s] = ~0u;
-    }
-    __syncthreads();
-    if (T.fail) {  // more distinct k-mers than slots, or a saturated k-mer: the whole region goes to the global table instead
-      for (uint32_t e = tid; e < nocc; e += WGB) reset_slot(tb.occ[e]);
-      __syncthreads();
-      if (tid == 0) {
-        bb.flag[r] = 2;
-        T.nocc = 0;
-      }
-      __syncthreads();
-      continue;
-    }
-    if (tid == 0) {
-      const uint32_t need = T.nout;
-      uint64_t gb, gb2 = 0;
-      uint32_t split = need;
-      if (out.block == 0) {
-        gb = atomicAdd((unsigned long long *)out.cursor, (unsigned long long)need);
-      } else {
-        // from this workgroup's current block first, then from fresh ones (thread 0 keeps the block in registers)
-        gb = blk_base;
-        split = need < blk_left ? need : (uint32_t)blk_left;
-        blk_base += split;
-        blk_left -= split;
-        const uint32_t rest = need - split;
-        if (rest) {
-          const uint64_t take = ((uint64_t)rest + out.block - 1) / out.block * out.block;
-          gb2 = atomicAdd((unsigned long long *)out.cursor, (unsigned long long)take);
-          blk_base = gb2 + rest;
-          blk_left = take - rest;
-        }
-      }
-      T.gbase_lo = (uint32_t)gb;
-      T.gbase_hi = (uint32_t)(gb >> 32);
-      T.gbase2_lo = (uint32_t)gb2;
-      T.gbase2_hi = (uint32_t)(gb2 >> 32);
-      T.split = split;
-      acc_entries += nocc;
-      acc_purged += nocc - need;
-      acc_sum += T.sum;
-      T.nocc = 0;  // every thread has its copy; the next region starts an empty list
-    }
-    __syncthreads();
-    KC_STAMP(3)  // vote + reserve
-    const uint64_t gbase = ((uint64_t)T.gbase_hi << 32) | T.gbase_lo, gbase2 = ((uint64_t)T.gbase2_hi << 32) | T.gbase2_lo;
-    const uint32_t split = T.split;
-    for (uint32_t e = tid; e < nocc; e += WGB) {
-      const uint32_t s = tb.occ[e];
-      const uint32_t p = tb.ext[(EW - 1) * SM + s];
-      if (p != ~0u) {
-        const uint32_t rank = p >> 20;
-        const uint64_t o = rank < split ? gbase + rank : gbase2 + (rank - split);
-        if (o < out.cap) {  // beyond the arrays: the host sees the cursor past cap and re-runs with more room
-          if (CP) {
-            out.keys[o] = cp_unpack_rec(keys32[s] << 6, r, gm);
-          } else {
+      const bool failed = T.fail[buf] != 0;  // more distinct k-mers than slots: the whole region goes to the global table instead
+      const uint64_t gbase = ((uint64_t)T.gbase_hi << 32) | T.gbase_lo, gbase2 = ((uint64_t)T.gbase2_hi << 32) | T.gbase2_lo;
+      const uint32_t split = T.split;
+      // S7 vote + S8 purge over the table, slot by slot; the survivors of a wave take their ranks from ONE add to the
+      // region's counter and are written straight to their places; every visited slot is left clean
+      for (uint32_t s0 = 0; s0 < S; s0 += WGB) {
+        const uint32_t s = s0 + tid;
+        bool taken = false;
+        if (s < S) taken = CP ? keys32[s] != 0xFFFFFFFFu : tb.keys[(NL - 1) * SM + s] != KEY_EMPTY;
+        bool keep = false;
+        uint32_t count = 0, l = 0, rr = 0;
+        uint32_t w[EW];
+        if (taken && !failed) {
 #pragma unroll
-            for (int w = 0; w < NL; w++) out.keys[o * NL + w] = tb.keys[w * SM + s];
-          }
-          out.counts[o] = (uint16_t)(p & 0xFFFFu);
+          for (int x = 0; x < EW; x++) w[x] = tb.ext[x * SM + s];
+          // the k-mer's count: every occurrence bumped exactly one of the left side's five counters (<= 65535: n is)
+          count = (w[0] & 0xFFFFu) + (w[0] >> 16) + (w[1] & 0xFFFFu) + (w[1] >> 16) + (w[EW == 6 ? 2 : 4] & 0xFFFFu);
           if (DUMP) {
+            keep = true;
+          } else if (count >= 2) {
+            const uint32_t lc[4] = {w[0] & 0xFFFFu, w[0] >> 16, w[1] & 0xFFFFu, w[1] >> 16};
+            constexpr int R0 = EW == 6 ? 3 : 2;
+            const uint32_t rc[4] = {w[R0] & 0xFFFFu, w[R0] >> 16, w[R0 + 1] & 0xFFFFu, w[R0 + 1] >> 16};
+            l = vote_ext(lc, count, dmin_thres);
+            rr = vote_ext(rc, count, dmin_thres);
+            keep = l < 4u && rr < 4u;
+          }
+          acc_entries++;
+        }
+        const uint64_t m = __ballot(keep);
+        if (m) {  // wave-uniform
+          const int leader = __ffsll((long long)m) - 1;
+          const uint32_t cnt = (uint32_t)__popcll(m);
+          uint64_t o = 0;
+          if (out.block != 0) {
+            uint32_t base = 0;
+            if ((int)lane_id() == leader) base = atomicAdd(&T.nout, cnt);
+            base = __shfl(base, leader);
+            const uint32_t rank = base + (uint32_t)__popcll(m & ((1ULL << lane_id()) - 1ULL));
+            o = rank < split ? gbase + rank : gbase2 + (rank - split);
+          } else {  // no blocks (dumps, tiny result sets): positions straight from the global cursor
+            unsigned long long base = 0;
+            if ((int)lane_id() == leader) base = atomicAdd((unsigned long long *)out.cursor, (unsigned long long)cnt);
+            base = __shfl(base, leader);
+            o = base + (uint64_t)__popcll(m & ((1ULL << lane_id()) - 1ULL));
+          }
+          if (keep && o < out.cap) {  // beyond the arrays: the host sees the cursor past cap and re-runs with more room
+            if (CP) {
+              out.keys[o] = cp_unpack_rec(keys32[s] << 6, r, gm);
+            } else {
 #pragma unroll
-            for (int x = 0; x < 8; x++) out.exts[o * 8 + x] = (uint16_t)ext_get<EW>(tb.ext, SM, s, x >> 2, x & 3);
-          } else {
-            out.left[o] = (uint8_t)("ACGT"[(p >> 16) & 3u]);
-            out.right[o] = (uint8_t)("ACGT"[(p >> 18) & 3u]);
+              for (int x = 0; x < NL; x++) out.keys[o * NL + x] = tb.keys[x * SM + s];
+            }
+            out.counts[o] = (uint16_t)count;
+            if (DUMP) {
+              constexpr int R0 = EW == 6 ? 3 : 2;
+#pragma unroll
+              for (int x = 0; x < 4; x++) {
+                out.exts[o * 8 + x] = (uint16_t)((w[x >> 1] >> (16 * (x & 1))) & 0xFFFFu);
+                out.exts[o * 8 + 4 + x] = (uint16_t)((w[R0 + (x >> 1)] >> (16 * (x & 1))) & 0xFFFFu);
+              }
+            } else {
+              out.left[o] = (uint8_t)("ACGT"[l & 3u]);
+              out.right[o] = (uint8_t)("ACGT"[rr & 3u]);
+            }
+          }
+          if (keep) {
+            acc_kept++;
+            acc_sum += count;
           }
         }
+        if (taken) reset_slot(s);  // leave the table clean for the next region
       }
-      reset_slot(s);  // leave the table clean for the next region
+      if (failed && tid == 0) {
+        bb.flag[r] = 2;
+        T.fail[buf] = 0;  // (this half is next used two regions on)
+      }
+      sink ^= touch;  // (first use of the touched word: by now it has arrived)
+      __syncthreads();
+      KC_STAMP(2)  // table pass + barrier
     }
-    __syncthreads();
-    KC_STAMP(4)  // write out + clean
+    r = rn;
+    buf ^= 1;
   }
   if (tid == 0) {
-    if (!DUMP) {
-      atomicAdd((unsigned long long *)&cb[CB_ENTRIES], (unsigned long long)acc_entries);
-      atomicAdd((unsigned long long *)&ctrs[CTR_PURGED], (unsigned long long)acc_purged);
-      atomicAdd((unsigned long long *)&ctrs[CTR_SUM_COUNTS], (unsigned long long)acc_sum);
-    }
+    settle();
     if (out.block) {
-      out.tails[2 * blockIdx.x] = blk_base;
-      out.tails[2 * blockIdx.x + 1] = blk_left;
+      out.tails[4 * blockIdx.x] = cur_base;
+      out.tails[4 * blockIdx.x + 1] = cur_left;
+      out.tails[4 * blockIdx.x + 2] = sp_base;
+      out.tails[4 * blockIdx.x + 3] = sp_left;
     }
   }
+  if (!DUMP) {
+    unsigned long long e = acc_entries, p = acc_entries - acc_kept, sm = acc_sum;
+    for (int o = 32; o > 0; o >>= 1) {
+      e += __shfl_down(e, o);
+      p += __shfl_down(p, o);
+      sm += __shfl_down(sm, o);
+    }
+    if (lane_id() == 0) {
+      if (e) atomicAdd((unsigned long long *)&cb[CB_ENTRIES], e);
+      if (p) atomicAdd((unsigned long long *)&ctrs[CTR_PURGED], p);
+      if (sm) atomicAdd((unsigned long long *)&ctrs[CTR_SUM_COUNTS], sm);
+    }
+  }
+  if (sink == 0x9E3779B9u && R == 0) cb[CB_DUMP] = sink;  // keeps the look-ahead loads alive; never true
 #ifdef KC_STAMPS
   if (stamp)
     for (int k = 0; k < 5; k++) atomicAdd((unsigned long long *)&cb[8 + k], tacc[k]);
@@ -1550,7 +1584,7 @@ __global__ __launch_bounds__(WGB, 8) void kc_count_kernel(Geom gm, BucketBufs bb
 // ---- closing the holes that block-wise output leaves (OutBufs::block) ------------------------------------------------
 // plan[0] = entries to move, plan[1] = holes below the final size, plan[2] = source runs; then the hole runs
 // (start, entries before it) and the source runs, PLAN_RUNS pairs each.
-constexpr uint32_t PLAN_RUNS = 1024;  // at most one hole per workgroup (<= 2 per CU) and one source run between two holes
+constexpr uint32_t PLAN_RUNS = 1024;  // at most two holes per workgroup (<= 2 workgroups per CU) and one source run between two holes
 constexpr size_t PLAN_WORDS = 4 + 4 * (size_t)(PLAN_RUNS + 1);
 
 // One workgroup.  T = the cursor (every block ever taken), holes = the unused tails; the final size is n = T - sum of

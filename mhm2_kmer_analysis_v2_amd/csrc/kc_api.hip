@@ -827,6 +827,9 @@ static int launch_l1_reads_t(kc_ctx *c, const ExtractArgs &a, uint64_t nsuper) {
   int rc = set_dyn_lds(kern, lds_l1_reads<NL>());
   if (rc) return rc;
   const unsigned grid = (unsigned)std::min<uint64_t>(c->gm.G, nsuper);
+#ifdef KC_ABLATE
+  c->gm.abl = getenv("KC_ABL_L1") ? (uint32_t)atoi(getenv("KC_ABL_L1")) : 0u;
+#endif
   KernelTimer kt(c, KT_L1_READS);
   hipLaunchKernelGGL(kern, dim3(grid), dim3(WGB), lds_l1_reads<NL>(), c->stream, a, c->gm, c->bb, nsuper, c->bk_rot, c->d_ctrs, c->d_cb);
   c->bk_rot = (uint32_t)((c->bk_rot + nsuper) % c->gm.G);
@@ -2037,6 +2040,9 @@ static int bk_level2_t(kc_ctx *c) {
   }
   hipLaunchKernelGGL(kc_bucket_prefix_kernel, dim3(1), dim3(WGB), 0, c->stream, c->gm, c->bb, fs, c->d_cb);
   c->num_gpu_calls++;
+#ifdef KC_ABLATE
+  c->gm.abl = getenv("KC_ABL_L2") ? (uint32_t)atoi(getenv("KC_ABL_L2")) : 0u;
+#endif
   if (fs.b_hi > fs.b_lo) {
     KernelTimer kt(c, KT_L2_SPLIT);
     hipLaunchKernelGGL(kern, dim3(std::min<unsigned>(fs.b_hi - fs.b_lo, (unsigned)c->num_cus)), dim3(WGB), lds_l2<NL>(), c->stream, c->gm, c->bb,
@@ -2121,6 +2127,9 @@ static int bk_count_t(kc_ctx *c, const OutBufs &ob) {
   // as many workgroups per CU as the LDS admits (at most 2: 1024 threads each), so that one region's barriers
   // and scans overlap another's inserts
   const unsigned per_cu = lds * 2 <= 160 * 1024 ? 2u : 1u;
+#ifdef KC_ABLATE
+  c->gm.abl = getenv("KC_ABL_COUNT") ? (uint32_t)atoi(getenv("KC_ABL_COUNT")) : 0u;
+#endif
   KernelTimer kt(c, KT_COUNT_REGIONS);
   hipLaunchKernelGGL(kern, dim3((unsigned)std::min<uint64_t>(R, (uint64_t)c->num_cus * per_cu)), dim3(WGB), lds, c->stream, c->gm, c->bb,
                      ob, c->cfg.dmin_thres, c->d_ctrs, c->d_cb);

@@ -67,7 +67,15 @@ struct Geom {
   uint32_t cp;                 // 0: records carry the k-mer itself, buckets come from its hash
   uint32_t la, lb;             // log2 P1, log2 P2
   uint32_t k2;                 // 2k: bits of the mixed k-mer
+#ifdef KC_ABLATE
+  uint32_t abl;                // experiment builds (-DKC_ABLATE): which part of a kernel to leave out (scripts/ablate.py)
+#endif
 };
+#ifdef KC_ABLATE
+#define KC_ABL(x, k) ((x).abl == (k))
+#else
+#define KC_ABL(x, k) false
+#endif
 
 struct BucketBufs {
   uint64_t *rec1;      // [G][A1] chunks of CH1 records
@@ -200,7 +208,9 @@ __device__ __forceinline__ uint32_t block_excl_scan(uint32_t v, ScanLDS &S) {
 // No LDS read sits inside a branch in the scatter and the copy-out: a read inside a conditional block is waited for at
 // the end of that block, which would put the reads of a thread's records one behind the other.
 struct SplitLDS {
-  uint32_t hist[2][PMAX];  // per-bucket counts of this round (double-buffered)
+  // per-bucket counts of this round (double-buffered); behind each, one word per lane for the positions that hold no
+  // record (hist_rank)
+  uint32_t hist[2][PMAX + 64];
   // what scatter and copy-out need to know about a destination's run, in one 16-byte read.  i = an element's index in
   // the sorted staging, s = where the run starts there (exclusive prefix):
   //   x, y = record index (relative to the owner's part of the arena) of element i, minus i, as seen from the chain's
@@ -211,6 +221,14 @@ struct SplitLDS {
   uint32_t arena_used;     // chunks taken from the owner's arena
   ScanLDS scan;
 };
+
+// Rank of a record inside its destination's run of this round: one LDS add, all of a thread's adds in flight together and
+// no branch around them.  A position without a record bumps a word of its own lane's behind the histogram -- chosen by
+// INDEX: a select between two LDS pointers is compiled into a branch around either address computation (seven vector and
+// five scalar instructions per record in round 2's kernels), a select between two indices is one v_cndmask.
+__device__ __forceinline__ uint32_t hist_rank(SplitLDS &L, int buf, uint32_t b, bool valid) {
+  return atomicAdd(&L.hist[buf][valid ? b : (uint32_t)PMAX + lane_id()], 1u);
+}
 
 // where the destinations of the current owner live
 #ifdef KC_STAMPS
@@ -234,6 +252,10 @@ struct ChainDest {
   uint32_t log2CH, LMAX;
   uint32_t arena_cap;   // chunks this owner may take
   uint32_t arena_base;  // id of the owner's first chunk
+#ifdef KC_ABLATE
+  uint32_t abl;         // experiment builds: see Geom::abl
+  uint32_t abl_a;       // experiment builds: records per 64 bytes of this destination
+#endif
 };
 
 // state of destination `tid`, kept in thread tid's registers (only that thread ever touches it)
@@ -297,7 +319,7 @@ __device__ __forceinline__ uint32_t split_stage(SplitLDS &L, uint64_t *sorted, u
   lds_barrier();
   KC_SPLIT_STAMP(2)  // scan + reserve
   const uint32_t total = L.scan.total;
-  {
+  if (!KC_ABL(D, 3)) {
     // all the run starts first, then all the writes; a position without a record goes to a slot of its lane's behind
     // the staging
     uint32_t pos[R];
@@ -325,6 +347,7 @@ __device__ __forceinline__ void split_copy_out(SplitLDS &L, const uint64_t *sort
   // copy out, U elements per thread and trip: first all their records, then all their destinations, then the stores
   constexpr int U = NL == 1 ? 4 : 2;
   const size_t arena0 = (size_t)D.arena_base << D.log2CH;
+  if (KC_ABL(D, 2) || KC_ABL(D, 3)) return;
   for (uint32_t i0 = tid; i0 < total; i0 += U * WGB) {
     uint64_t r[U][NL];
     uint32_t b[U];
@@ -351,7 +374,14 @@ __device__ __forceinline__ void split_copy_out(SplitLDS &L, const uint64_t *sort
       const bool live = i < total, fits = j < (d[u].z >> 16);
       // x and y are "index minus staging position" modulo 2^32: the sum must wrap in 32 bits before it is widened
       const uint32_t at = (j < d[u].w ? d[u].x : d[u].y) + i;
-      if (live && fits) store(arena0 + at, r[u]);
+#ifdef KC_ABLATE
+      if (KC_ABL(D, 4)) {  // timing only (wrong results): every run starts on a 64-byte boundary and is whole 64-byte blocks long
+        const uint32_t am = D.abl_a - 1u, nfit = ((d[u].z >> 16) + (D.abl_a >> 1)) & ~am;
+        const uint32_t at2 = at - ((at - j) & am);
+        if (live && j < nfit) store(arena0 + at2, r[u]);
+      } else
+#endif
+      if (live && fits && !KC_ABL(D, 1)) store(arena0 + at, r[u]);
       spill |= live && !fits;
     }
     if (__any(spill)) {  // rare: a chain or the arena is full
@@ -416,7 +446,6 @@ __global__ __launch_bounds__(WGB) void kc_arena_probe_kernel(uint64_t *arena, si
 struct L1LDS {
   TileLDS<TileSuper> tile;
   SplitLDS sp;
-  uint32_t idle[64];  // what the positions without a k-mer add to (one word per lane: no two lanes share one)
 };
 
 template <int NL>
@@ -432,6 +461,10 @@ __device__ __forceinline__ ChainDest l1_dest(const Geom &gm, const BucketBufs &b
   D.LMAX = gm.L1MAX;
   D.arena_cap = gm.A1;
   D.arena_base = 0;
+#ifdef KC_ABLATE
+  D.abl = gm.abl;
+  D.abl_a = 8 / NL;
+#endif
   return D;
 }
 
@@ -527,7 +560,6 @@ __global__ __launch_bounds__(WGB) void kc_l1_reads_kernel(ExtractArgs a, Geom gm
   D.tprev = &tprev_;
 #endif
   ChainState cst = split_load_state(L.sp, P1, bb.cnt1 + (size_t)g * P1, D.chain, D.LMAX, D.log2CH, bb.used1[g]);
-  if (tid < 64) L.idle[tid] = 0;
   __syncthreads();
   uint32_t n_ins = 0;
   int buf = 0;
@@ -589,7 +621,7 @@ __global__ __launch_bounds__(WGB) void kc_l1_reads_kernel(ExtractArgs a, Geom gm
 #pragma unroll
       for (int j = 0; j < RPOS; j++) {
         const bool valid = br[j] != ~0u;
-        const uint32_t rank = atomicAdd(valid ? &L.sp.hist[buf][br[j] & (PMAX - 1)] : &L.idle[lane_id()], 1u);
+        const uint32_t rank = hist_rank(L.sp, buf, br[j] & (PMAX - 1), valid);
         br[j] = valid ? (br[j] | (rank << (SHORT ? 16 : 10))) : ~0u;
         n_ins += valid ? 1u : 0u;
       }
@@ -742,7 +774,6 @@ __global__ __launch_bounds__(WGB) void kc_bin_reads_kernel(ExtractArgs a, uint64
 // ---- level 1 from records (receiver side of the shard exchange) -------------------------------------
 struct L1RLDS {
   SplitLDS sp;
-  uint32_t idle[64];  // what the lanes past the end add to (one word per lane)
 };
 
 template <int NL, bool CP>
@@ -756,7 +787,6 @@ __global__ __launch_bounds__(WGB) void kc_l1_records_kernel(const uint64_t *recs
   const uint32_t g = (blockIdx.x + rot) % gm.G, P1 = gm.P1;
   const ChainDest D = l1_dest<NL>(gm, bb, g);
   ChainState cst = split_load_state(L.sp, P1, bb.cnt1 + (size_t)g * P1, D.chain, D.LMAX, D.log2CH, bb.used1[g]);
-  if (tid < 64) L.idle[tid] = 0;
   __syncthreads();
   const uint64_t per_round = (uint64_t)WGB * RPOS;
   const uint64_t nrounds = (n + per_round - 1) / per_round;
@@ -790,7 +820,7 @@ __global__ __launch_bounds__(WGB) void kc_l1_records_kernel(const uint64_t *recs
       const bool valid = rd * per_round + (uint64_t)j * WGB + tid < n;
       if (CP) rec[j][0] = cp_mix_rec(rec[j][0], gm);
       const uint32_t b = CP ? cp_b1(rec[j][0], gm) : hash_b1(rec_hash<NL>(rec[j]), gm);
-      const uint32_t rank = atomicAdd(valid ? &L.sp.hist[buf][b] : &L.idle[lane_id()], 1u);
+      const uint32_t rank = hist_rank(L.sp, buf, b, valid);
       br[j] = valid ? (b | (rank << 10)) : ~0u;
       n_ins += valid ? 1u : 0u;
     }
@@ -867,7 +897,6 @@ __global__ __launch_bounds__(WGB) void kc_bucket_prefix_kernel(Geom gm, BucketBu
 struct L2LDS {
   SplitLDS sp;
   uint32_t pre[GMAX + 1];  // prefix of the bucket's G segment lengths (+ those of its flat sources)
-  uint32_t idle[64];       // what the lanes past the end add to (one word per lane)
   uint64_t flo[FLAT_MAX];  // shard flow: where the bucket's run starts in each flat source
 };
 
@@ -885,7 +914,6 @@ __global__ __launch_bounds__(WGB) void kc_l2_split_kernel(Geom gm, BucketBufs bb
   constexpr int RPOS = Rnd<NL>::RPOS;
   const int tid = threadIdx.x;
   const uint32_t P1 = gm.P1, P2 = gm.P2, G = gm.G;
-  if (tid < 64) L.idle[tid] = 0;
   const uint32_t GT = FL ? G + fs.F : G;  // segments of a bucket
   for (uint32_t b1 = (FL ? fs.b_lo : 0u) + blockIdx.x; b1 < (FL ? fs.b_hi : P1); b1 += gridDim.x) {
     // prefix over the segments of this bucket
@@ -908,6 +936,10 @@ __global__ __launch_bounds__(WGB) void kc_l2_split_kernel(Geom gm, BucketBufs bb
     D.LMAX = gm.L2MAX;
     D.arena_base = bb.base2[b1];
     D.arena_cap = bb.base2[b1 + 1] - bb.base2[b1];
+#ifdef KC_ABLATE
+    D.abl = gm.abl;
+    D.abl_a = CP ? 16 : 8 / NL;
+#endif
 #ifdef KC_STAMPS
     unsigned long long tprev_ = __builtin_amdgcn_s_memtime();
     D.stamps = cb + 8;
@@ -979,7 +1011,7 @@ __global__ __launch_bounds__(WGB) void kc_l2_split_kernel(Geom gm, BucketBufs bb
         uint32_t b;
         if constexpr (CR) b = br[j] & (PMAX - 1);
         else b = CP ? cp_b2(rec[j][0], gm) : hash_b2(rec_hash<NL>(rec[j]), gm);
-        const uint32_t rank = atomicAdd(valid ? &L.sp.hist[buf][b] : &L.idle[lane_id()], 1u);
+        const uint32_t rank = hist_rank(L.sp, buf, b, valid);
         if constexpr (CR) br[j] = valid ? (br[j] | (rank << 16)) : ~0u;
         else br[j] = valid ? (b | (rank << 10)) : ~0u;
       }
@@ -1410,12 +1442,12 @@ __global__ __launch_bounds__(WGB, 8) void kc_count_kernel(Geom gm, BucketBufs bb
           for (int j = 0; j < BATCH; j++) {
             const uint32_t v = (i0 + (uint32_t)j * WGB + tid) < n ? 1u : 0u;
             const uint32_t r0 = rec32[j], key = r0 >> 6;
-            if (!__any(v)) continue;  // past the end of the region for the whole wave
+            if (!__any(v) || KC_ABL(gm, 2)) continue;  // past the end of the region for the whole wave
             const uint32_t s = lds_probe32(keys32, S - 1u, key, key & (S - 1u), ((key >> tb.lgS) << 1) | 1u, v, failed);
             const uint32_t le = r0 & 7u, re = (r0 >> 3) & 7u;
             // only lanes that hold a record touch the counters: the idle lanes of a wave all re-read record 0, and 64
             // atomic adds of zero to one LDS word are serialised
-            if (v) ext_count<EW>(tb, s, le, re);
+            if (v && !KC_ABL(gm, 1)) ext_count<EW>(tb, s, le, re);
           }
           if (failed) T.fail[buf] = 1;
         } else if constexpr (NL == 1) {
@@ -1479,7 +1511,7 @@ __global__ __launch_bounds__(WGB, 8) void kc_count_kernel(Geom gm, BucketBufs bb
         bool keep = false;
         uint32_t count = 0, l = 0, rr = 0;
         uint32_t w[EW];
-        if (taken && !failed) {
+        if (taken && !failed && !KC_ABL(gm, 3)) {
 #pragma unroll
           for (int x = 0; x < EW; x++) w[x] = tb.ext[x * SM + s];
           // the k-mer's count: every occurrence bumped exactly one of the left side's five counters (<= 65535: n is)

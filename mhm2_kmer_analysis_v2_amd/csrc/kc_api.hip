@@ -824,12 +824,12 @@ static int launch_l1_reads_t(kc_ctx *c, const ExtractArgs &a, uint64_t nsuper) {
   auto kern = use_cp<NL>(c) ? (k21 ? (sh ? kc_l1_reads_kernel<NL, FMT, NL == 1, true, K21> : kc_l1_reads_kernel<NL, FMT, NL == 1, false, K21>)
                                    : (sh ? kc_l1_reads_kernel<NL, FMT, NL == 1, true, 0> : kc_l1_reads_kernel<NL, FMT, NL == 1, false, 0>))
                             : (sh ? kc_l1_reads_kernel<NL, FMT, false, true, 0> : kc_l1_reads_kernel<NL, FMT, false, false, 0>);
-  int rc = set_dyn_lds(kern, lds_l1_reads<NL>());
-  if (rc) return rc;
   const unsigned grid = (unsigned)std::min<uint64_t>(c->gm.G, nsuper);
 #ifdef KC_ABLATE
   c->gm.abl = getenv("KC_ABL_L1") ? (uint32_t)atoi(getenv("KC_ABL_L1")) : 0u;
 #endif
+  int rc = set_dyn_lds(kern, lds_l1_reads<NL>());
+  if (rc) return rc;
   KernelTimer kt(c, KT_L1_READS);
   hipLaunchKernelGGL(kern, dim3(grid), dim3(WGB), lds_l1_reads<NL>(), c->stream, a, c->gm, c->bb, nsuper, c->bk_rot, c->d_ctrs, c->d_cb);
   c->bk_rot = (uint32_t)((c->bk_rot + nsuper) % c->gm.G);

@@ -157,6 +157,18 @@ __device__ __forceinline__ uint64_t rec_hash(const uint64_t (&rec)[NL]) {
 // which would serialise the global loads and stores these kernels keep in flight across their LDS phases.
 __device__ __forceinline__ void lds_barrier() { asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory"); }
 
+// The thread id as a value the compiler cannot trace back to the id register.  Addresses that depend only on the thread
+// (its word of the histogram, its entry of dst[], its chain) are otherwise computed once before the outermost loop, kept
+// in registers for the whole kernel and, in kernels that use every register they may, SPILLED -- and a reload from scratch is
+// a vector-memory load whose wait (vmcnt(0): the counter is in order) is a wait for every prefetch load and every copy-out
+// store the wave has in flight.  Round 2's level-2 kernel reloaded two such addresses per round: one before writing
+// dst[] and one right behind the next round's sixteen prefetch loads.  Recomputing them costs an instruction or two.
+__device__ __forceinline__ int fresh_tid() {
+  int t = threadIdx.x;
+  asm volatile("" : "+v"(t));
+  return t;
+}
+
 // ---- workgroup exclusive scan over WGB values --------------------------------------------------
 struct ScanLDS {
   uint32_t wsum[32];
@@ -282,7 +294,7 @@ __device__ __forceinline__ uint32_t split_stage(SplitLDS &L, uint64_t *sorted, u
                                                 const uint32_t (&br)[R], const ChainDest &D, ChainState &st) {
   static_assert(R * WGB <= 32768, "positions in the staging must fit 16 bits");
   static_assert(RS == 10 || R * WGB <= 65536, "ranks must fit the bits above RS");
-  const int tid = threadIdx.x;
+  const int tid = fresh_tid();
   KC_SPLIT_STAMP(1)  // barrier after the histogram
   const uint32_t v = ((uint32_t)tid < P) ? L.hist[buf][tid] : 0u;
   const uint32_t excl = block_excl_scan(v, L.scan);
@@ -320,19 +332,24 @@ __device__ __forceinline__ uint32_t split_stage(SplitLDS &L, uint64_t *sorted, u
   KC_SPLIT_STAMP(2)  // scan + reserve
   const uint32_t total = L.scan.total;
   if (!KC_ABL(D, 3)) {
-    // all the run starts first, then all the writes; a position without a record goes to a slot of its lane's behind
-    // the staging
-    uint32_t pos[R];
+    // all the run starts first, then all the writes (eight records at a time: sixteen starts in flight cost the level-2
+    // kernel registers it does not have); a position without a record goes to a slot of its lane's behind the staging
+    constexpr int H = R < 8 ? R : 8;
 #pragma unroll
-    for (int j = 0; j < R; j++) pos[j] = L.dst[br[j] & (PMAX - 1)].z;
+    for (int j0 = 0; j0 < R; j0 += H) {
+      uint32_t pos[H];
 #pragma unroll
-    for (int j = 0; j < R; j++) {
-      const uint32_t p = br[j] != ~0u ? (pos[j] & 0xFFFFu) + (br[j] >> RS) : (uint32_t)(R * WGB) + lane_id();
-      uint64_t r[NL];
-      rec_of(j, r);
+      for (int j = 0; j < H; j++) pos[j] = L.dst[br[j0 + j] & (PMAX - 1)].z;
 #pragma unroll
-      for (int w = 0; w < NL; w++) sorted[(size_t)p * NL + w] = r[w];
-      if (sbucket) sbucket[p] = (uint16_t)(br[j] & (PMAX - 1));
+      for (int j = 0; j < H; j++) {
+        const uint32_t bj = br[j0 + j];
+        const uint32_t p = bj != ~0u ? (pos[j] & 0xFFFFu) + (bj >> RS) : (uint32_t)(R * WGB) + lane_id();
+        uint64_t r[NL];
+        rec_of(j0 + j, r);
+#pragma unroll
+        for (int w = 0; w < NL; w++) sorted[(size_t)p * NL + w] = r[w];
+        if (sbucket) sbucket[p] = (uint16_t)(bj & (PMAX - 1));
+      }
     }
   }
   lds_barrier();
@@ -343,7 +360,7 @@ __device__ __forceinline__ uint32_t split_stage(SplitLDS &L, uint64_t *sorted, u
 template <int NL, class BucketFn, class OvfFn, class StoreFn>
 __device__ __forceinline__ void split_copy_out(SplitLDS &L, const uint64_t *sorted, const uint16_t *sbucket, uint32_t total, const ChainDest &D,
                                                BucketFn bucket_of, OvfFn overflow, StoreFn store) {
-  const int tid = threadIdx.x;
+  const int tid = fresh_tid();
   // copy out, U elements per thread and trip: first all their records, then all their destinations, then the stores
   constexpr int U = NL == 1 ? 4 : 2;
   const size_t arena0 = (size_t)D.arena_base << D.log2CH;

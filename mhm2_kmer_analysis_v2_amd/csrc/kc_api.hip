@@ -109,6 +109,10 @@ struct kc_ctx {
   bool started;       // something was submitted since create/reset
   Geom gm;
   BucketBufs bb;
+  // arrays of an earlier geometry of this context (another k of a sweep), kept so that a later one can take them over
+  // instead of allocating again: [i] pairs with the i-th pointer of BucketBufs (bk_slots)
+  struct { void *p; size_t bytes; } bk_pool[11];
+  size_t bk_held[11];    // bytes behind the pointers bb holds now
   uint64_t *d_cb, *h_cb;
   bool bk_spilled;       // earlier buffer-fulls of this pass were counted and merged into the global table (bk_spill_pass)
   uint64_t expect_base;  // CTR_EXPECT when the buffer was last emptied: what is buffered now is CTR_EXPECT - expect_base
@@ -138,7 +142,7 @@ struct kc_ctx {
 };
 
 // ---- kernel timing (HIP events on the launch stream) --------------------------------------------
-static void bk_free(kc_ctx *c);
+static void bk_free(kc_ctx *c, bool keep);
 static void host_pipe_free(kc_ctx *c);
 static void shard_free(kc_ctx *c);
 
@@ -432,7 +436,7 @@ extern "C" void kc_destroy(kc_ctx *c) {
   if (c->d_sm_out) (void)hipFree(c->d_sm_out);
   if (c->d_sm_ctr) (void)hipFree(c->d_sm_ctr);
   host_pipe_free(c);
-  bk_free(c);
+  bk_free(c, false);
   shard_free(c);
   if (c->d_cb) (void)hipFree(c->d_cb);
   if (c->h_cb) (void)hipHostFree(c->h_cb);
@@ -503,7 +507,7 @@ extern "C" int kc_reset(kc_ctx *c, int new_k) {
   // new k among the one-word ones: whether the records are compact, and how, depends on k)
   if (c->bk_ready) {
     if (c->nl != old_nl || (c->nl == 1 && new_k != old_k)) {
-      bk_free(c);
+      bk_free(c, true);  // the next geometry takes the arrays over where they are large enough
     } else {
       const size_t R = (size_t)c->gm.P1 * c->gm.P2;
       HIPCHK(hipMemsetAsync(c->bb.cnt1, 0, (size_t)c->gm.G * c->gm.P1 * 4, c->stream));
@@ -531,14 +535,60 @@ static uint32_t count_smax(int nl) {
   }
 }
 
-static void bk_free(kc_ctx *c) {
-  BucketBufs &b = c->bb;
-  void *ptrs[] = {b.rec1, b.chain1, b.cnt1, b.used1, b.rec2, b.chain2, b.cnt2, b.base2, b.flag, b.ovf1, b.ovf2};
-  for (void *p : ptrs)
-    if (p) (void)hipFree(p);
-  memset(&b, 0, sizeof(b));
+// the pointers of BucketBufs, in the order of kc_ctx::bk_pool
+static void bk_slots(BucketBufs &b, void ***out) {
+  void **ptrs[11] = {(void **)&b.rec1, (void **)&b.chain1, (void **)&b.cnt1, (void **)&b.used1, (void **)&b.rec2, (void **)&b.chain2,
+                     (void **)&b.cnt2, (void **)&b.base2, (void **)&b.flag, (void **)&b.ovf1, (void **)&b.ovf2};
+  for (int i = 0; i < 11; i++) out[i] = ptrs[i];
+}
+
+// Give up the current geometry.  keep: its arrays stay with the context (kc_reset to another k, kc_set_tuning) and the
+// next geometry takes over every one that is large enough -- BASELINE config 5's sweep k = 21, 33, 55, 77 keeps its
+// arenas resident in HBM: they are allocated once per record width at most, and a width seen before allocates nothing.
+static void bk_free(kc_ctx *c, bool keep = false) {
+  void **slot[11];
+  bk_slots(c->bb, slot);
+  for (int i = 0; i < 11; i++) {
+    void *p = *slot[i];
+    if (p && keep && c->bk_held[i] > c->bk_pool[i].bytes) {  // the larger of the two stays
+      if (c->bk_pool[i].p) (void)hipFree(c->bk_pool[i].p);
+      c->bk_pool[i].p = p;
+      c->bk_pool[i].bytes = c->bk_held[i];
+    } else if (p) {
+      (void)hipFree(p);
+    }
+    if (!keep && c->bk_pool[i].p) {
+      (void)hipFree(c->bk_pool[i].p);
+      c->bk_pool[i].p = nullptr;
+      c->bk_pool[i].bytes = 0;
+    }
+    c->bk_held[i] = 0;
+  }
+  memset(&c->bb, 0, sizeof(c->bb));
   c->bk_ready = false;
   c->bk_bytes = 0;
+}
+
+// `bytes` of device memory for the i-th array of the bucket buffers: what the context kept from an earlier geometry
+// when that is large enough (*reused), else a fresh allocation
+static int bk_take(kc_ctx *c, int i, void **out, size_t bytes, bool *reused = nullptr) {
+  if (reused) *reused = false;
+  if (c->bk_pool[i].p && c->bk_pool[i].bytes >= bytes) {
+    *out = c->bk_pool[i].p;
+    c->bk_held[i] = c->bk_pool[i].bytes;
+    c->bk_pool[i].p = nullptr;
+    c->bk_pool[i].bytes = 0;
+    if (reused) *reused = true;
+    return KC_OK;
+  }
+  if (c->bk_pool[i].p) {  // too small: make room for its successor
+    (void)hipFree(c->bk_pool[i].p);
+    c->bk_pool[i].p = nullptr;
+    c->bk_pool[i].bytes = 0;
+  }
+  HIPCHK(hipMalloc(out, bytes));
+  c->bk_held[i] = bytes;
+  return KC_OK;
 }
 
 static uint32_t ilog2(uint64_t v) {
@@ -709,17 +759,21 @@ static int bk_init(kc_ctx *c) {
   const size_t w = (size_t)c->nl * 8;
   const size_t nseg = (size_t)g.G * g.P1;
   const size_t rec1_bytes = (size_t)g.G * g.A1 * CH1 * w, rec2_bytes = (size_t)g.A2 * CH2 * (g.cp ? 4 : w);
-  HIPCHK(hipMalloc((void **)&b.rec1, rec1_bytes));
-  HIPCHK(hipMalloc((void **)&b.chain1, nseg * g.L1MAX * 4));
-  HIPCHK(hipMalloc((void **)&b.cnt1, nseg * 4));
-  HIPCHK(hipMalloc((void **)&b.used1, (size_t)g.G * 4));
-  HIPCHK(hipMalloc((void **)&b.rec2, rec2_bytes));
-  HIPCHK(hipMalloc((void **)&b.chain2, (size_t)R * g.L2MAX * 4));
-  HIPCHK(hipMalloc((void **)&b.cnt2, (size_t)R * 4));
-  HIPCHK(hipMalloc((void **)&b.base2, ((size_t)g.P1 + 1) * 4));
-  HIPCHK(hipMalloc((void **)&b.flag, (size_t)R * 4));
-  HIPCHK(hipMalloc((void **)&b.ovf1, b.ovf1_cap * w));
-  HIPCHK(hipMalloc((void **)&b.ovf2, b.ovf2_cap * w));
+  bool rec1_reused = false, rec2_reused = false;
+  {
+    int rc = bk_take(c, 0, (void **)&b.rec1, rec1_bytes, &rec1_reused);
+    if (!rc) rc = bk_take(c, 1, (void **)&b.chain1, nseg * g.L1MAX * 4);
+    if (!rc) rc = bk_take(c, 2, (void **)&b.cnt1, nseg * 4);
+    if (!rc) rc = bk_take(c, 3, (void **)&b.used1, (size_t)g.G * 4);
+    if (!rc) rc = bk_take(c, 4, (void **)&b.rec2, rec2_bytes, &rec2_reused);
+    if (!rc) rc = bk_take(c, 5, (void **)&b.chain2, (size_t)R * g.L2MAX * 4);
+    if (!rc) rc = bk_take(c, 6, (void **)&b.cnt2, (size_t)R * 4);
+    if (!rc) rc = bk_take(c, 7, (void **)&b.base2, ((size_t)g.P1 + 1) * 4);
+    if (!rc) rc = bk_take(c, 8, (void **)&b.flag, (size_t)R * 4);
+    if (!rc) rc = bk_take(c, 9, (void **)&b.ovf1, b.ovf1_cap * w);
+    if (!rc) rc = bk_take(c, 10, (void **)&b.ovf2, b.ovf2_cap * w);
+    if (rc) return rc;
+  }
   HIPCHK(hipMemsetAsync(b.cnt1, 0, nseg * 4, c->stream));
   HIPCHK(hipMemsetAsync(b.used1, 0, (size_t)g.G * 4, c->stream));
   HIPCHK(hipMemsetAsync(b.cnt2, 0, (size_t)R * 4, c->stream));
@@ -729,12 +783,18 @@ static int bk_init(kc_ctx *c) {
   // pattern whose speed depends on how the driver happened to back the allocation: pick_fast_arena
   {
     const char *pe = getenv("KC_ARENA_PROBE");
-    if (!(pe && pe[0] == '0') && g.G >= (uint32_t)c->num_cus && (size_t)g.A1 * CH1 * c->nl >= ((size_t)8 << 20)) {  // the benchmark's sizes
-      int rc2 = scrub_allocation(c, &b.rec2, rec2_bytes);
-      if (rc2) return rc2;
+    // (for every arena of a GiB or more: below that a stage is over before the difference shows)
+    if (!(pe && pe[0] == '0') && rec1_bytes >= ((size_t)1 << 30)) {
+      // (an arena taken over from an earlier geometry has been written and chosen already)
+      if (!rec2_reused) {
+        int rc2 = scrub_allocation(c, &b.rec2, rec2_bytes);
+        if (rc2) return rc2;
+      }
       // (level 2's arena was tried too: its probe does not predict level 2's time, which moves by only 4 %)
-      int rc = pick_fast_arena(c, &b.rec1, rec1_bytes, g.G, "level 1");
-      if (rc) return rc;
+      if (!rec1_reused) {
+        int rc = pick_fast_arena(c, &b.rec1, rec1_bytes, g.G, "level 1");
+        if (rc) return rc;
+      }
     }
   }
   if (getenv("KC_DEBUG_ADDR"))
@@ -2111,6 +2171,7 @@ static int bk_build_regions(kc_ctx *c) {
     c->bk_bytes += (need - c->bb.ovf2_cap) * (size_t)c->nl * 8;
     c->bb.ovf2 = bigger;
     c->bb.ovf2_cap = need;
+    c->bk_held[10] = need * (size_t)c->nl * 8;
     HIPCHK(hipMemsetAsync(c->d_cb + CB_OVF2, 0, 2 * 8, c->stream));  // OVF2, FATAL
   }
   c->bk_level2 = true;
@@ -2578,7 +2639,7 @@ extern "C" int kc_set_tuning(kc_ctx *c, const kc_tuning *t) {
   HIPCHK(hipSetDevice(c->cfg.device));
   HIPCHK(hipStreamSynchronize(c->stream));
   c->tuning = *t;
-  bk_free(c);  // the geometry is chosen again at the first submit
+  bk_free(c, true);  // the geometry is chosen again at the first submit
   return KC_OK;
 }
 

@@ -1,6 +1,7 @@
 """Parity at sizes the oracle cannot reach in seconds, through size-independent properties.  BASELINE config 2 is
-50 M reads at k=21 and that is what runs by default (KC_FULLSIZE_READS overrides it); the two- and three-word
-paths of configs 4 and 5 (k=51, k=77) run at KC_FULLSIZE_READS_LONG reads (10 M by default):
+50 M reads at k=21 and that is what runs by default (KC_FULLSIZE_READS overrides it); config 4 (k=51) runs at its full
+12 M reads (KC_FULLSIZE_READS_LONG), config 5's other legs (k=33, 55, 77) at one GPU's share of its 106 M reads
+(KC_FULLSIZE_READS_SWEEP, 13.25 M), and its multi-k sweep with the arenas kept resident at 10 M reads per leg:
   * every k-mer occurrence with two neighbours is inserted exactly once (count known in closed form);
   * the bucketed path and the global-table path -- two unrelated implementations -- agree on the result set
     (checksum of checksums), on the number of distinct k-mers and on the sum of counts;
@@ -20,7 +21,9 @@ from oracle import cpu_oracle as O
 pytestmark = pytest.mark.gpu
 
 NREADS = int(os.environ.get("KC_FULLSIZE_READS", "50000000"))
-NREADS_LONG = int(os.environ.get("KC_FULLSIZE_READS_LONG", "10000000"))
+NREADS_LONG = int(os.environ.get("KC_FULLSIZE_READS_LONG", "12000000"))    # BASELINE config 4: 1.8 Gbases
+NREADS_SWEEP = int(os.environ.get("KC_FULLSIZE_READS_SWEEP", "13250000"))  # BASELINE config 5: 15.9 Gbases over 8 GPUs
+NREADS_RESET = int(os.environ.get("KC_FULLSIZE_READS_RESET", "10000000"))
 L = 150
 
 
@@ -33,7 +36,7 @@ def checksum(kc):
     return int(np.bitwise_xor.reduce(h)) if len(cc) else 0, int(h.sum(dtype=np.uint64)), len(cc)
 
 
-@pytest.mark.parametrize("k,nreads", [(21, NREADS), (51, NREADS_LONG), (77, NREADS_LONG)])
+@pytest.mark.parametrize("k,nreads", [(21, NREADS), (51, NREADS_LONG), (33, NREADS_SWEEP), (55, NREADS_SWEEP), (77, NREADS_SWEEP)])
 def test_full_size_properties(k, nreads):
     import torch
     p = pkg.synth_params()
@@ -68,6 +71,48 @@ def test_full_size_properties(k, nreads):
     got, _ = pkg.analyze_kmers(k, 33, db[:n_small * L], dq[:n_small * L], do[:n_small + 1])
     for g, w in zip(got, want):
         assert g.shape == w.shape and (g == w).all()
+
+
+def test_multi_k_sweep_at_size_keeps_the_arenas():
+    """BASELINE config 5: k = 21, 33, 55, 77 (and back) through ONE context with kc_reset(k) (the reference runs one k
+    per process, src/main.cpp:167-190: the sweep is this repo's harness).  Every leg's result equals a fresh context's
+    (checksum of checksums, distinct k-mers, sum of counts); the device memory the context holds does not grow when it
+    comes back to a record width it has seen, and a wider record takes the narrower one's arrays over where they fit."""
+    import torch
+    nreads = NREADS_RESET
+    p = pkg.synth_params()
+    db = torch.empty(nreads * L, dtype=torch.uint8, device="cuda")
+    dq = torch.empty(nreads * L, dtype=torch.uint8, device="cuda")
+    do = torch.empty(nreads + 1, dtype=torch.int64, device="cuda")
+
+    def sizes(k):
+        return dict(max_elems=int(64 * 4_000_000 + nreads * L * 0.005 * k * 1.05) + (1 << 20),
+                    max_kmers_buffered=int(nreads * (L - 21 - 1) * 1.02) + (1 << 20))
+
+    fresh = {}
+    for k in (21, 33, 55, 77):
+        with pkg.KmerCounter(k, **sizes(k)) as kc:
+            if k == 21:
+                kc.synth_reads_device(db, dq, do, nreads, params=p)
+            kc.submit_reads(db, dq, do, nreads=nreads)
+            st = kc.stats()
+            assert st["kmers_inserted"] == nreads * (L - k - 1) and st["num_dropped"] == 0
+            fresh[k] = (checksum(kc), st["num_unique"], st["sum_counts"], st["num_purged"])
+    torch.cuda.synchronize()
+    free0 = torch.cuda.mem_get_info()[0]
+    with pkg.KmerCounter(21, **sizes(77)) as kc:
+        held = {}       # record width -> device memory in use after the first leg of that width
+        for k in (21, 33, 55, 77, 55, 21, 33):
+            kc.reset(k)
+            kc.submit_reads(db, dq, do, nreads=nreads)
+            st = kc.stats()
+            assert (checksum(kc), st["num_unique"], st["sum_counts"], st["num_purged"]) == fresh[k], k
+            assert st["kmers_inserted"] == nreads * (L - k - 1) and st["num_dropped"] == 0
+            torch.cuda.synchronize()
+            used = free0 - torch.cuda.mem_get_info()[0]
+            if kc.nl in held:  # a width seen before: no arena is allocated again (1 GiB of slack: the result arrays differ)
+                assert used <= max(held.values()) + (1 << 30), (k, used, held)
+            held.setdefault(kc.nl, used)
 
 
 def skewed_reads(nreads, rl, k, genome_len, seed):
@@ -144,7 +189,7 @@ def test_heavy_hitters_match_the_oracle():
     assert st["num_unique"] == ost["unique"] and st["num_dropped"] == 0
 
 
-@pytest.mark.parametrize("k,R", [(21, 2), (21, 4), (51, 2)])
+@pytest.mark.parametrize("k,R", [(21, 2), (21, 4), (21, 8), (51, 2)])
 def test_single_pass_shard_flow_at_size(k, R):
     """The single-pass shard flow (kc_shard_extract / kc_shard_reserve / kc_shard_commit) with R shards on one device,
     KC_FULLSIZE_READS_LONG reads in all: the union of the shards is the result of one context over all the reads (same

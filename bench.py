@@ -22,7 +22,7 @@ sys.path.insert(0, ROOT)
 
 ALG_BYTES_PER_KMER = {1: 34.0, 2: 46.0, 3: 58.0, 4: 70.0}  # SURVEY.md section 8d contract constants, by num_longs
 HBM_PEAK_GBPS = 8000.0  # MI355X_MICROARCH.md: 8.0 TB/s spec
-PROFILE = "profiles/r02_pmc_50Mreads.json"  # rocprofv3 PMC passes of this same command (scripts/pmc_profile.sh)
+PROFILE = "profiles/r03_pmc_50Mreads.json"  # rocprofv3 PMC passes of this same command (scripts/pmc_profile.sh)
 
 
 def own_alg_bytes(kernel, nl, k, read_len, results_per_raw):
@@ -73,7 +73,10 @@ def pmc_traffic(nreads, k, tuned):
     out = {}
     for name, ctr in prof.items():
         if "FETCH_SIZE" in ctr and "WRITE_SIZE" in ctr:
-            out[name] = (2.0 * ctr["FETCH_SIZE"] + ctr["WRITE_SIZE"]) * 1024.0
+            ent = {"bytes": (2.0 * ctr["FETCH_SIZE"] + ctr["WRITE_SIZE"]) * 1024.0}
+            if ctr.get("TCC_HIT_sum", 0) + ctr.get("TCC_MISS_sum", 0) > 0:
+                ent["l2_hit"] = ctr["TCC_HIT_sum"] / (ctr["TCC_HIT_sum"] + ctr["TCC_MISS_sum"])
+            out[name] = ent
     return out, PROFILE
 
 
@@ -220,10 +223,16 @@ def main():
                                shard_buckets=buckets)
 
     kc = make_counter(flow == "single-pass")
-    if flow == "single-pass" and a.shard_flow == "auto" and kc.shard_capacity() < est_unique:
-        kc.close()
-        flow = "records"
-        kc = make_counter(False)
+    if flow == "single-pass" and a.shard_flow == "auto":
+        # decided together: a shard's capacity depends on how many buckets it owns, which differs between ranks when the
+        # fan-out is no multiple of the shard count, and ranks on different flows would wait for each other for ever
+        cap = torch.tensor([kc.shard_capacity()], dtype=torch.int64, device=dev)
+        if world > 1:
+            dist.all_reduce(cap, op=dist.ReduceOp.MIN)
+        if int(cap.item()) < est_unique:
+            kc.close()
+            flow = "records"
+            kc = make_counter(False)
     # one explicit stream for everything (torch ops, RCCL enqueue order, the library's kernels): torch's default
     # stream is the null handle, which the library would read as "use your own stream"
     stream = torch.cuda.Stream(device=dev)
@@ -336,13 +345,19 @@ def main():
                 ent.update({"alg_bytes_per_kmer": round(own, 3), "achieved_GBps": gbps, "frac": gbps / HBM_PEAK_GBPS})
             tr = next((v for n, v in traffic.items() if name in n), None)
             if tr is not None:
-                ent.update({"traffic_bytes_per_step": tr, "traffic_GBps": tr / (ms_step * 1e-3) / 1e9})
+                ent.update({"traffic_bytes_per_step": tr["bytes"], "traffic_GBps": tr["bytes"] / (ms_step * 1e-3) / 1e9})
+                if "l2_hit" in tr:
+                    ent["l2_hit"] = round(tr["l2_hit"], 4)
             kernels.append(ent)
         dom = kernels[0] if kernels else None
         roof = {"bound": "hbm", "scope": "stage (all kernels of a step, wall time)", "achieved": achieved, "peak": HBM_PEAK_GBPS,
                 "unit": "GB/s", "frac": achieved / HBM_PEAK_GBPS, "alg_bytes_per_kmer": ALG_BYTES_PER_KMER[nl],
                 "kmers_per_step": raw_per_rank, "kernel": dom["name"] if dom else None,
-                "traffic": sum(traffic.values()) if traffic else None, "traffic_unit": "bytes per step, all kernels",
+                # (only the kernels that ran inside the timed steps: the profile also holds the set-up fills, the read
+                # generator and the arena probe, which are no part of a step)
+                "traffic": (sum(e["traffic_bytes_per_step"] for e in kernels if "traffic_bytes_per_step" in e) or None) if traffic else None,
+                "traffic_unit": "bytes per step, summed over the kernels of a step",
+                "l2_hit": {e["name"]: e["l2_hit"] for e in kernels if "l2_hit" in e} or None,
                 "traffic_source": traffic_src, "kernels": kernels,
                 "kernels_ms": {n: round(v[1] / a.steps, 3) for n, v in ktimes.items()}}
         out = {

@@ -511,7 +511,7 @@ extern "C" int kc_reset(kc_ctx *c, int new_k) {
     } else {
       const size_t R = (size_t)c->gm.P1 * c->gm.P2;
       HIPCHK(hipMemsetAsync(c->bb.cnt1, 0, (size_t)c->gm.G * c->gm.P1 * 4, c->stream));
-      HIPCHK(hipMemsetAsync(c->bb.used1, 0, (size_t)c->gm.G * 4, c->stream));
+      HIPCHK(hipMemsetAsync(c->bb.used1, 0, (size_t)c->gm.G * 2 * 4, c->stream));
       HIPCHK(hipMemsetAsync(c->bb.cnt2, 0, R * 4, c->stream));
       HIPCHK(hipMemsetAsync(c->bb.flag, 0, R * 4, c->stream));
     }
@@ -764,7 +764,7 @@ static int bk_init(kc_ctx *c) {
     int rc = bk_take(c, 0, (void **)&b.rec1, rec1_bytes, &rec1_reused);
     if (!rc) rc = bk_take(c, 1, (void **)&b.chain1, nseg * g.L1MAX * 4);
     if (!rc) rc = bk_take(c, 2, (void **)&b.cnt1, nseg * 4);
-    if (!rc) rc = bk_take(c, 3, (void **)&b.used1, (size_t)g.G * 4);
+    if (!rc) rc = bk_take(c, 3, (void **)&b.used1, (size_t)g.G * 2 * 4);
     if (!rc) rc = bk_take(c, 4, (void **)&b.rec2, rec2_bytes, &rec2_reused);
     if (!rc) rc = bk_take(c, 5, (void **)&b.chain2, (size_t)R * g.L2MAX * 4);
     if (!rc) rc = bk_take(c, 6, (void **)&b.cnt2, (size_t)R * 4);
@@ -775,7 +775,7 @@ static int bk_init(kc_ctx *c) {
     if (rc) return rc;
   }
   HIPCHK(hipMemsetAsync(b.cnt1, 0, nseg * 4, c->stream));
-  HIPCHK(hipMemsetAsync(b.used1, 0, (size_t)g.G * 4, c->stream));
+  HIPCHK(hipMemsetAsync(b.used1, 0, (size_t)g.G * 2 * 4, c->stream));
   HIPCHK(hipMemsetAsync(b.cnt2, 0, (size_t)R * 4, c->stream));
   HIPCHK(hipMemsetAsync(b.flag, 0, (size_t)R * 4, c->stream));
   HIPCHK(hipMemsetAsync(c->d_cb, 0, CB_COUNT * 8, c->stream));
@@ -877,6 +877,14 @@ template <int NL> static bool use_cp(const kc_ctx *c) { return NL == 1 && c->gm.
 template <int NL, int FMT>
 static int launch_l1_reads_t(kc_ctx *c, const ExtractArgs &a, uint64_t nsuper) {
   const bool sh = c->cfg.rank_n > 1 && !c->sh.extracting;  // the shard flow ships whole buckets instead of testing k-mers
+  // shard flow: the chains of the buckets other shards own are emptied after every block and live at the top of the
+  // writers' arenas (ChainDest::own_lo); everywhere else every bucket is the context's own
+  c->gm.own_lo = 0;
+  c->gm.own_hi = PMAX;
+  if (c->sh.extracting && c->cfg.rank_n > 1) {
+    c->gm.own_lo = shard_first_bucket((uint32_t)c->cfg.rank_me, c->gm.P1, (uint32_t)c->cfg.rank_n);
+    c->gm.own_hi = shard_first_bucket((uint32_t)c->cfg.rank_me + 1, c->gm.P1, (uint32_t)c->cfg.rank_n);
+  }
   // compact records at k = 21 (MHM2's first and only one-word k of its default sweep, src/options.hpp:80): the
   // instantiation made for that k; any other k takes the general one
   constexpr int K21 = NL == 1 ? 21 : 0;
@@ -976,6 +984,8 @@ static int launch_bin_reads(kc_ctx *c, const ExtractArgs &a, uint64_t ntiles, in
 template <int NL>
 static int launch_l1_records_t(kc_ctx *c, const uint64_t *recs, uint64_t n) {
   auto kern = use_cp<NL>(c) ? kc_l1_records_kernel<NL, NL == 1> : kc_l1_records_kernel<NL, false>;
+  c->gm.own_lo = 0;
+  c->gm.own_hi = PMAX;
   int rc = set_dyn_lds(kern, lds_l1_records<NL>());
   if (rc) return rc;
   const uint64_t per_round = (uint64_t)WGB * Rnd<NL>::RPOS;
@@ -1024,7 +1034,7 @@ static int bk_drain_to_table(kc_ctx *c) {
   if (rc) return rc;
   HIPCHK(hipGetLastError());
   HIPCHK(hipMemsetAsync(c->bb.cnt1, 0, (size_t)c->gm.G * c->gm.P1 * 4, c->stream));
-  HIPCHK(hipMemsetAsync(c->bb.used1, 0, (size_t)c->gm.G * 4, c->stream));
+  HIPCHK(hipMemsetAsync(c->bb.used1, 0, (size_t)c->gm.G * 2 * 4, c->stream));
   HIPCHK(hipMemsetAsync(c->d_cb, 0, CB_COUNT * 8, c->stream));
   c->table_mode = true;
   return KC_OK;
@@ -1821,6 +1831,7 @@ static int shard_extract_pack(kc_ctx *c, bool anything, uint64_t *d_segments, ui
   HIPCHK(hipStreamSynchronize(c->stream));
   const uint64_t *h_totals = c->sh.h_plan, *h_flags = h_totals + SHARD_MAX, *h_loose = h_flags + SHARD_MAX;
   uint64_t *h_hdr = c->sh.h_plan + 3 * SHARD_MAX;
+  bool patched = false;
   for (uint32_t d = 0; d < n; d++) {
     if (d == me) continue;
     if (h_flags[d]) {
@@ -1835,7 +1846,11 @@ static int shard_extract_pack(kc_ctx *c, bool anything, uint64_t *d_segments, ui
       HIPCHK(hipMemcpyAsync(d_segments + (size_t)d * seg_words + 1, &h_hdr[d], 8, hipMemcpyHostToDevice, c->stream));
     }
     c->sh.sent += h_totals[d] + h_loose[d];
+    patched = patched || h_loose[d] != 0;
   }
+  // the contract of kc_shard_extract: when it returns, every byte of the segments is in place (the caller may hand
+  // them to another stream or to the network at once) -- the header patches above included
+  if (patched) HIPCHK(hipStreamSynchronize(c->stream));
   return KC_OK;
 }
 
@@ -1918,6 +1933,19 @@ extern "C" int kc_shard_commit(kc_ctx *c, const uint64_t *d_segment, uint64_t nw
   if (hdr[0] != shard_signature(c) || nb != nbo || shard_header_words(nb) + (nrec + loose) * (uint64_t)c->nl != nwords) {
     snprintf(g_last_error, sizeof(g_last_error), "kc_shard_commit: not a segment for this shard (made by a context with another k, geometry or shard count?)");
     return KC_ERR_INVALID_ARG;
+  }
+  {
+    // the per-bucket counts must add up to the records the header announces: level 2 takes every bucket's address from
+    // them, and a truncated or corrupt segment would otherwise be read past its end at finalize
+    std::vector<uint32_t> counts(nb);
+    HIPCHK(hipMemcpy(counts.data(), d_segment + SHARD_HDR, (size_t)nb * 4, hipMemcpyDeviceToHost));
+    uint64_t sum = 0;
+    for (uint32_t v : counts) sum += v;
+    if (sum != nrec) {
+      snprintf(g_last_error, sizeof(g_last_error), "kc_shard_commit: the segment's bucket counts add up to %llu records, its header says %llu",
+               (unsigned long long)sum, (unsigned long long)nrec);
+      return KC_ERR_INVALID_ARG;
+    }
   }
   if (c->sh.F >= std::min<uint32_t>(FLAT_MAX, GMAX - c->gm.G)) {
     snprintf(g_last_error, sizeof(g_last_error), "shard flow: %u segments received in one pass is the limit: use larger blocks", c->sh.F);
@@ -2513,7 +2541,7 @@ static int bk_spill_pass(kc_ctx *c) {
   if (rc) return rc;
   const size_t R = (size_t)c->gm.P1 * c->gm.P2;
   HIPCHK(hipMemsetAsync(c->bb.cnt1, 0, (size_t)c->gm.G * c->gm.P1 * 4, c->stream));
-  HIPCHK(hipMemsetAsync(c->bb.used1, 0, (size_t)c->gm.G * 4, c->stream));
+  HIPCHK(hipMemsetAsync(c->bb.used1, 0, (size_t)c->gm.G * 2 * 4, c->stream));
   HIPCHK(hipMemsetAsync(c->bb.cnt2, 0, R * 4, c->stream));
   HIPCHK(hipMemsetAsync(c->bb.flag, 0, R * 4, c->stream));
   HIPCHK(hipMemsetAsync(c->d_cb, 0, CB_COUNT * 8, c->stream));

@@ -67,6 +67,7 @@ struct Geom {
   uint32_t cp;                 // 0: records carry the k-mer itself, buckets come from its hash
   uint32_t la, lb;             // log2 P1, log2 P2
   uint32_t k2;                 // 2k: bits of the mixed k-mer
+  uint32_t own_lo, own_hi;     // level-1 buckets this shard owns (every one unless the context is in the shard flow): ChainDest::own_lo
 #ifdef KC_ABLATE
   uint32_t abl;                // experiment builds (-DKC_ABLATE): which part of a kernel to leave out (scripts/ablate.py)
 #endif
@@ -81,7 +82,7 @@ struct BucketBufs {
   uint64_t *rec1;      // [G][A1] chunks of CH1 records
   uint32_t *chain1;    // [G*P1][L1MAX] chunk index within the writer's arena
   uint32_t *cnt1;      // [G*P1] records in the chain
-  uint32_t *used1;     // [G] chunks taken from each writer's arena
+  uint32_t *used1;     // [2 * G] chunks taken from each writer's arena: [g] from the bottom, [G + g] from the top (ChainDest::own_lo)
   uint64_t *rec2;      // [A2] chunks of CH2 records
   uint32_t *chain2;    // [P1*P2][L2MAX] chunk index in rec2
   uint32_t *cnt2;      // [P1*P2] records in the chain
@@ -230,7 +231,8 @@ struct SplitLDS {
   //          either the index is linear in i);  z = s | how many of the run's records found room << 16;
   //   w = how many of those still go into the old last chunk
   uint4 dst[PMAX];
-  uint32_t arena_used;     // chunks taken from the owner's arena
+  uint32_t arena_used;     // chunks taken from the bottom of the owner's arena
+  uint32_t arena_top;      // ... from its top (shard flow: the chains that leave with every block, ChainDest::own_lo)
   ScanLDS scan;
 };
 
@@ -264,6 +266,11 @@ struct ChainDest {
   uint32_t log2CH, LMAX;
   uint32_t arena_cap;   // chunks this owner may take
   uint32_t arena_base;  // id of the owner's first chunk
+  // Destinations [own_lo, own_hi) take their chunks from the bottom of the arena, the others from its top.  The shard
+  // flow (kc_shard.hpp) empties every chain of a bucket another shard owns after every block: those chains live at the
+  // top, and giving the top back whole (kc_shard_release_kernel) recycles their chunks, the partly filled last ones
+  // included -- a bump allocator that only grew lost about half a chunk per foreign chain and block.
+  uint32_t own_lo, own_hi;
 #ifdef KC_ABLATE
   uint32_t abl;         // experiment builds: see Geom::abl
   uint32_t abl_a;       // experiment builds: records per 64 bytes of this destination
@@ -307,11 +314,28 @@ __device__ __forceinline__ uint32_t split_stage(SplitLDS &L, uint64_t *sorted, u
     const uint32_t have = (base + CHm) >> D.log2CH;
     uint32_t k = ((base + fit + CHm) >> D.log2CH) - have, a = 0;
     if (k) {
-      a = atomicAdd(&L.arena_used, k);
-      if (a + k > D.arena_cap) {  // arena exhausted: use what is left of it, the rest overflows
-        k = a < D.arena_cap ? D.arena_cap - a : 0;
-        const uint64_t cap = ((uint64_t)(have + k) << D.log2CH) - base;
-        if ((uint64_t)fit > cap) fit = (uint32_t)cap;
+      const bool own = (uint32_t)tid >= D.own_lo && (uint32_t)tid < D.own_hi;
+      if (own) {
+        a = atomicAdd(&L.arena_used, k);
+        const uint32_t left = D.arena_cap - min(D.arena_cap, L.arena_top);  // (the top only moves between launches of a shard's blocks)
+        if (a + k > left) {  // arena exhausted: use what is left of it, the rest overflows
+          k = a < left ? left - a : 0;
+          const uint64_t cap = ((uint64_t)(have + k) << D.log2CH) - base;
+          if ((uint64_t)fit > cap) fit = (uint32_t)cap;
+        }
+      } else {
+        // k consecutive chunks below what the top has taken so far; the bottom is whatever the launch started with
+        // plus what it takes meanwhile: the two ends may only meet in a launch that is about to overflow anyway, and
+        // then both sides stop at the other's starting point of this launch
+        const uint32_t t = atomicAdd(&L.arena_top, k);
+        const uint32_t left = D.arena_cap - min(D.arena_cap, L.arena_used);
+        if (t + k > left) {
+          k = 0;
+          const uint64_t cap = ((uint64_t)have << D.log2CH) - base;
+          if ((uint64_t)fit > cap) fit = (uint32_t)cap;
+        } else {
+          a = D.arena_cap - t - k;
+        }
       }
       uint32_t *ch = D.chain + (size_t)tid * D.LMAX + have;
       for (uint32_t i = 0; i < k; i++) ch[i] = D.arena_base + a + i;
@@ -423,7 +447,7 @@ __device__ __forceinline__ void store_words(uint64_t *arena, size_t i, const uin
 
 // load the persistent state of this owner's P chains (before its first round)
 __device__ __forceinline__ ChainState split_load_state(SplitLDS &L, uint32_t P, const uint32_t *cnt, const uint32_t *chain,
-                                                       uint32_t LMAX, uint32_t log2CH, uint32_t used) {
+                                                       uint32_t LMAX, uint32_t log2CH, uint32_t used, uint32_t top = 0) {
   const int tid = threadIdx.x;
   ChainState st;
   st.cur = 0;
@@ -435,7 +459,10 @@ __device__ __forceinline__ ChainState split_load_state(SplitLDS &L, uint32_t P, 
     L.hist[0][tid] = 0;
     L.hist[1][tid] = 0;
   }
-  if (tid == 0) L.arena_used = used;
+  if (tid == 0) {
+    L.arena_used = used;
+    L.arena_top = top;
+  }
   return st;
 }
 
@@ -478,6 +505,8 @@ __device__ __forceinline__ ChainDest l1_dest(const Geom &gm, const BucketBufs &b
   D.LMAX = gm.L1MAX;
   D.arena_cap = gm.A1;
   D.arena_base = 0;
+  D.own_lo = gm.own_lo;
+  D.own_hi = gm.own_hi;
 #ifdef KC_ABLATE
   D.abl = gm.abl;
   D.abl_a = 8 / NL;
@@ -576,7 +605,7 @@ __global__ __launch_bounds__(WGB) void kc_l1_reads_kernel(ExtractArgs a, Geom gm
   D.stamps = cb + 8;
   D.tprev = &tprev_;
 #endif
-  ChainState cst = split_load_state(L.sp, P1, bb.cnt1 + (size_t)g * P1, D.chain, D.LMAX, D.log2CH, bb.used1[g]);
+  ChainState cst = split_load_state(L.sp, P1, bb.cnt1 + (size_t)g * P1, D.chain, D.LMAX, D.log2CH, bb.used1[g], bb.used1[gm.G + g]);
   __syncthreads();
   uint32_t n_ins = 0;
   int buf = 0;
@@ -675,7 +704,10 @@ __global__ __launch_bounds__(WGB) void kc_l1_reads_kernel(ExtractArgs a, Geom gm
     }
   }
   if ((uint32_t)tid < P1) bb.cnt1[(size_t)g * P1 + tid] = cst.cur;
-  if (tid == 0) bb.used1[g] = min(L.sp.arena_used, gm.A1);
+  if (tid == 0) {
+    bb.used1[g] = min(L.sp.arena_used, gm.A1);
+    bb.used1[gm.G + g] = min(L.sp.arena_top, gm.A1);
+  }
   for (int o = 32; o > 0; o >>= 1) n_ins += __shfl_down(n_ins, o);
   if (lane_id() == 0 && n_ins) atomicAdd((unsigned long long *)&ctrs[CTR_INSERTED], (unsigned long long)n_ins);
 }
@@ -803,7 +835,7 @@ __global__ __launch_bounds__(WGB) void kc_l1_records_kernel(const uint64_t *recs
   const int tid = threadIdx.x;
   const uint32_t g = (blockIdx.x + rot) % gm.G, P1 = gm.P1;
   const ChainDest D = l1_dest<NL>(gm, bb, g);
-  ChainState cst = split_load_state(L.sp, P1, bb.cnt1 + (size_t)g * P1, D.chain, D.LMAX, D.log2CH, bb.used1[g]);
+  ChainState cst = split_load_state(L.sp, P1, bb.cnt1 + (size_t)g * P1, D.chain, D.LMAX, D.log2CH, bb.used1[g], bb.used1[gm.G + g]);
   __syncthreads();
   const uint64_t per_round = (uint64_t)WGB * RPOS;
   const uint64_t nrounds = (n + per_round - 1) / per_round;
@@ -861,7 +893,10 @@ __global__ __launch_bounds__(WGB) void kc_l1_records_kernel(const uint64_t *recs
     buf ^= 1;
   }
   if ((uint32_t)tid < P1) bb.cnt1[(size_t)g * P1 + tid] = cst.cur;
-  if (tid == 0) bb.used1[g] = min(L.sp.arena_used, gm.A1);
+  if (tid == 0) {
+    bb.used1[g] = min(L.sp.arena_used, gm.A1);
+    bb.used1[gm.G + g] = min(L.sp.arena_top, gm.A1);
+  }
   for (int o = 32; o > 0; o >>= 1) n_ins += __shfl_down(n_ins, o);
   if (lane_id() == 0 && n_ins) {
     atomicAdd((unsigned long long *)&ctrs[CTR_INSERTED], (unsigned long long)n_ins);
@@ -953,6 +988,8 @@ __global__ __launch_bounds__(WGB) void kc_l2_split_kernel(Geom gm, BucketBufs bb
     D.LMAX = gm.L2MAX;
     D.arena_base = bb.base2[b1];
     D.arena_cap = bb.base2[b1 + 1] - bb.base2[b1];
+    D.own_lo = 0;
+    D.own_hi = PMAX;
 #ifdef KC_ABLATE
     D.abl = gm.abl;
     D.abl_a = CP ? 16 : 8 / NL;

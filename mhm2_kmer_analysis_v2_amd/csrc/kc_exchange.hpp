@@ -59,6 +59,7 @@ class ShardExchange {
   uint64_t *h_all = nullptr;                       // pinned
   hipEvent_t arrived[2] = {nullptr, nullptr};      // side stream: the block has landed
   hipEvent_t consumed[2] = {nullptr, nullptr};     // compute stream: whatever read send[i] / recv[i] is done
+  hipEvent_t extracted = nullptr;                  // compute stream: the block's segments are complete
   bool used[2] = {false, false};
   struct Piece { const uint64_t *p; uint64_t words; };
   struct Pending {
@@ -103,10 +104,10 @@ class ShardExchange {
       pending.pieces.clear();
     } else {
       if (pending.n_own) KCX_KC(kc_insert_records(ctx, send[b] + (uint64_t)me * seg * nl, pending.n_own));
-      if (pending.n_recv) {
-        KCX_HIP(hipStreamWaitEvent(compute, arrived[b], 0));
-        KCX_KC(kc_insert_records(ctx, recv[b], pending.n_recv));
-      }
+      // always: the extraction of two blocks on overwrites send[b] on this stream, and the side stream's ncclSend of
+      // this block may still be reading it -- also when this rank received nothing
+      KCX_HIP(hipStreamWaitEvent(compute, arrived[b], 0));
+      if (pending.n_recv) KCX_KC(kc_insert_records(ctx, recv[b], pending.n_recv));
       KCX_HIP(hipEventRecord(consumed[b], compute));
       received += pending.n_own + pending.n_recv;
     }
@@ -139,6 +140,7 @@ class ShardExchange {
       KCX_HIP(hipEventCreateWithFlags(&arrived[b], hipEventDisableTiming));
       KCX_HIP(hipEventCreateWithFlags(&consumed[b], hipEventDisableTiming));
     }
+    KCX_HIP(hipEventCreateWithFlags(&extracted, hipEventDisableTiming));
     KCX_HIP(hipMalloc((void **)&d_counts, (size_t)n * 8));
     KCX_HIP(hipMalloc((void **)&d_all, (size_t)n * n * 8));
     KCX_HIP(hipHostMalloc((void **)&h_all, (size_t)n * n * 8, hipHostMallocDefault));
@@ -154,6 +156,7 @@ class ShardExchange {
       if (arrived[b]) (void)hipEventDestroy(arrived[b]);
       if (consumed[b]) (void)hipEventDestroy(consumed[b]);
     }
+    if (extracted) (void)hipEventDestroy(extracted);
     if (d_counts) (void)hipFree(d_counts);
     if (d_all) (void)hipFree(d_all);
     if (h_all) (void)hipHostFree(h_all);
@@ -181,6 +184,11 @@ class ShardExchange {
     } else if (nreads) {
       KCX_KC(kc_extract_partition(ctx, bases, quals, offsets, nreads, on_device, send[b], seg, counts.data()));
     }
+    // kc_shard_extract / kc_extract_partition return with the segments complete on the compute stream (they synchronize
+    // it); the side stream is ordered behind the compute stream all the same, so that the transfers below never depend
+    // on that detail
+    KCX_HIP(hipEventRecord(extracted, compute));
+    KCX_HIP(hipStreamWaitEvent(side, extracted, 0));
     // everybody's sizes: N x N, row s = what rank s sends to each shard
     KCX_HIP(hipMemcpyAsync(d_counts, counts.data(), (size_t)n * 8, hipMemcpyHostToDevice, side));
     KCX_NCCL(ncclAllGather(d_counts, d_all, (size_t)n, ncclUint64, comm, side));

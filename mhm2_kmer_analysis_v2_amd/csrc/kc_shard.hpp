@@ -115,14 +115,20 @@ __global__ __launch_bounds__(WGB) void kc_shard_pack_kernel(Geom gm, BucketBufs 
   }
 }
 
-// after the pack: the foreign chains start again empty (their chunks stay taken until the context is reset), and the
-// records that left no longer count as this shard's
+// after the pack: the foreign chains start again empty and the records that left no longer count as this shard's.  The
+// chains of foreign buckets take their chunks from the top of every writer's arena (ChainDest::own_lo): once every one of
+// them is empty the top is given back whole, so a shard can take any number of blocks.
 __global__ void kc_shard_release_kernel(Geom gm, BucketBufs bb, uint32_t me, uint32_t n, const uint64_t *totals, const uint64_t *flags,
                                         uint64_t *ctrs) {
   const size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
   if (i < (size_t)gm.G * gm.P1) {
     const uint32_t d = shard_of_bucket((uint32_t)(i % gm.P1), gm.P1, n);
     if (d != me && !flags[d]) bb.cnt1[i] = 0;
+  }
+  if (i < gm.G) {
+    bool all = true;  // (a destination whose segment was too small keeps its chains: nothing is given back then)
+    for (uint32_t d = 0; d < n; d++) all = all && (d == me || !flags[d]);
+    if (all) bb.used1[gm.G + i] = 0;
   }
   if (i == 0) {
     uint64_t gone = 0;

@@ -12,10 +12,11 @@ from test_gpu_parity import PATHS, arrays, assert_same, oracle_run
 pytestmark = pytest.mark.gpu
 
 
-def run_shards(reads, quals, k, R, tuning, blocks=2, max_kmers_buffered=0):
+def run_shards(reads, quals, k, R, tuning, blocks=2, max_kmers_buffered=0, time_kernels=False):
     """Every 'rank' extracts its slice of the reads in `blocks` blocks; segments travel by a device copy."""
     import torch
-    shards = [pkg.KmerCounter(k, rank_me=r, rank_n=R, tuning=tuning, max_kmers_buffered=max_kmers_buffered) for r in range(R)]
+    shards = [pkg.KmerCounter(k, rank_me=r, rank_n=R, tuning=tuning, max_kmers_buffered=max_kmers_buffered, time_kernels=time_kernels)
+              for r in range(R)]
     nl = shards[0].rec_nl
     total = sum(max(0, len(r) - k - 1) for r in reads)
     seg_words = total * nl + 2048
@@ -93,6 +94,34 @@ def test_shard_flow_overflow_records_travel_loose(k, tuning):
         s.close()
 
 
+@pytest.mark.parametrize("k,R", [(21, 2), (21, 4), (51, 3)])
+def test_many_small_blocks_do_not_use_the_arena_up(k, R):
+    """Every block empties the chains of the buckets other shards own.  Their chunks come from the top of the writers'
+    arenas and the top is given back after every block (ChainDest::own_lo, kc_shard_release_kernel): forty blocks through
+    arenas with room for little more than the reads themselves must neither overflow nor spill a record to the global
+    table (a bump allocator that only grew lost half a chunk per foreign chain and block)."""
+    rng = np.random.default_rng(300 + k + R)
+    reads, quals = random_reads(rng, 2400, min_len=60, max_len=150, genome_len=5000)
+    b, q, offs = arrays(reads, quals)
+    want, _, wst = oracle_run(b, q, offs, k)
+    total = sum(max(0, len(r) - k - 1) for r in reads)
+    # per writer: the share of one shard's reads in 16-record chunks, plus one open chunk per bucket and a little slack
+    W, P = 2, 16
+    arena1 = (total // R) // (W * 16) + 2 * P + 8
+    tuning = dict(writers=W, p1=P, p2=16, slots=1024, chunk1=16, arena1=arena1, ovf_capacity=1 << 16)
+    shards, shipped, _ = run_shards(reads, quals, k, R, tuning, blocks=40, time_kernels=True)
+    assert shipped > 0
+    parts = [s.sorted_results() for s in shards]
+    assert_same(union(parts), want)
+    st = [s.stats() for s in shards]
+    assert sum(x["kmers_inserted"] for x in st) == total
+    # nothing took the fallback kernels (overflow records and flagged regions to the global table): the fast path held
+    # all forty blocks
+    for s in shards:
+        assert "kc_flagged_to_table_kernel" not in s.kernel_times(), s.kernel_times()
+        s.close()
+
+
 def test_single_shard_is_the_plain_flow():
     k = 21
     rng = np.random.default_rng(5)
@@ -137,6 +166,20 @@ def test_shard_flow_errors():
     with pytest.raises(pkg.KcError) as e:
         c.shard_commit(dst, w)
     assert e.value.status == -1
+    a.close()
+    c.close()
+    # a segment whose bucket counts do not add up to its header's record count is refused, not read past its end
+    a = pkg.KmerCounter(k, rank_me=0, rank_n=2, tuning=PATHS["compact"])
+    c = pkg.KmerCounter(k, rank_me=1, rank_n=2, tuning=PATHS["compact"])
+    words = a.shard_extract(b, q, offs, big, 1 << 18)
+    w = int(words[1])
+    dst = c.shard_reserve(w)
+    dst.copy_(big[(1 << 18):(1 << 18) + w])
+    dst[4] += 1  # the first two u32 counts live in word 4 (behind the four header words)
+    torch.cuda.synchronize()
+    with pytest.raises(pkg.KcError) as e:
+        c.shard_commit(dst, w)
+    assert e.value.status == -1 and "add up" in str(e.value)
     a.close()
     c.close()
 

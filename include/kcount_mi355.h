@@ -272,6 +272,20 @@ int kc_build_supermers(kc_ctx *ctx, const char *seqs, uint64_t len, int on_devic
  */
 int kc_submit_packed_supermers(kc_ctx *ctx, const uint8_t *packed, uint64_t len, int on_device);
 
+/* The contig k-mer pass (dead in the proxy; the backend surface is complete with it):
+ * HashTableInserter::init_ctg_kmers (kmer_dht.hpp:103, kcount_cpu.cpp:472-475; HashTableGPUDriver::init_ctg_kmers,
+ * gpu_hash_table.hpp:158) -- room for max_ctg_kmers distinct contig k-mers.  Call before kc_finalize. */
+int kc_begin_ctg_kmers(kc_ctx *ctx, uint64_t max_ctg_kmers);
+/* SeqBlockInserter::process_seq(ctg->seq, depth) + insert_supermer in the contig pass (kcount.cpp:129,
+ * kcount_cpu.cpp:357-407; insert_supermer_block with depths, gpu_hash_table.cpp:655-695): a '_'-joined block of contigs
+ * and, per character, the depth of its contig (the layout of SeqBlockInserterState::depth_block, kcount_gpu.cpp:74-91).
+ * kc_finalize then returns what the reference's insert_into_local_hashtable would after inserting the contigs behind
+ * the reads: the reads' results, plus the contig k-mers that are not among them, whose occurrences agree on both
+ * extensions (both bases) and all have a depth of 2 or more, with the smallest depth as their count (kc_ctg.hpp).
+ * KC_ERR_BAD_BASE for a character outside ACGTN (the reference DIEs), KC_ERR_CAPACITY when more distinct k-mers came than
+ * kc_begin_ctg_kmers made room for. */
+int kc_submit_ctg_block(kc_ctx *ctx, const char *seqs, const uint16_t *depths, uint64_t len, int on_device);
+
 /* KmerDHT::flush_updates -> HashTableInserter::flush_inserts (kmer_dht.cpp:252-258): wait for submitted work. */
 int kc_flush(kc_ctx *ctx);
 

@@ -90,6 +90,8 @@ SYMBOLS = {
     "kc_flush": (C.c_int, [C.c_void_p]),
     "kc_finalize": (C.c_int, [C.c_void_p, C.POINTER(kc_result)]),
     "kc_copy_results": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]),
+    "kc_begin_ctg_kmers": (C.c_int, [C.c_void_p, C.c_uint64]),
+    "kc_submit_ctg_block": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_uint64, C.c_int]),
     "kc_copy_results_entries": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p]),
     "kc_lookup": (C.c_int, [C.c_void_p, C.c_void_p, C.c_uint64, C.c_int, C.c_void_p, C.c_void_p, C.c_void_p]),
     "kc_dump_table": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.POINTER(C.c_uint64)]),

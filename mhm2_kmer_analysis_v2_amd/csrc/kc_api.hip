@@ -21,6 +21,7 @@
 #include "kc_bucketed.hpp"
 #include "kc_shard.hpp"
 #include "kc_supermer.hpp"
+#include "kc_ctg.hpp"
 
 using namespace kc;
 
@@ -74,9 +75,10 @@ struct kc_ctx {
   struct {
     uint8_t *d_bases[2], *d_quals[2], *h_bases[2], *h_quals[2];
     uint64_t *d_offs[2], *h_offs[2];
-    hipEvent_t copied[2], consumed[2];
+    hipEvent_t copied[2], consumed[2], half[2];
+    uint32_t lead_b[2], lead_q[2];  // bytes in front of a slot's first read (the copy started on a page boundary of the source)
     bool used[2];
-    hipStream_t copy_stream;
+    hipStream_t copy_stream, copy_stream2;  // a block's bytes cross PCIe as two concurrent copies (two DMA engines)
     size_t cap_bytes, cap_reads;
     bool ready;
   } hp;
@@ -89,6 +91,11 @@ struct kc_ctx {
   bool finalized;
   uint32_t *d_index;  // lookup index over the results (built on first kc_lookup)
   uint64_t index_cap;
+  // the contig pass (kc_ctg.hpp): a table of the contigs' k-mers, merged into the results by kc_finalize
+  Table ctg_table;
+  uint64_t ctg_cap;
+  uint64_t *d_ctg_status;  // [0] a character outside the alphabet was seen, [1] entries
+  uint64_t ctg_attempted, ctg_new;
   kc_synth_table *d_synth;
   // scratch of the reference-wire entry points (kc_build_supermers, kc_submit_packed_supermers)
   uint8_t *d_sm_bytes;    // block / unpacked block
@@ -401,6 +408,15 @@ static void free_index(kc_ctx *c) {
   c->index_cap = 0;
 }
 
+static void free_ctg(kc_ctx *c) {
+  if (c->ctg_table.keys) (void)hipFree(c->ctg_table.keys);
+  if (c->ctg_table.vals) (void)hipFree(c->ctg_table.vals);
+  if (c->d_ctg_status) (void)hipFree(c->d_ctg_status);
+  memset(&c->ctg_table, 0, sizeof(c->ctg_table));
+  c->d_ctg_status = nullptr;
+  c->ctg_cap = c->ctg_attempted = c->ctg_new = 0;
+}
+
 static void free_results(kc_ctx *c) {
   free_index(c);
   if (c->d_out_keys) (void)hipFree(c->d_out_keys);
@@ -436,6 +452,7 @@ extern "C" void kc_destroy(kc_ctx *c) {
   if (c->d_sm_out) (void)hipFree(c->d_sm_out);
   if (c->d_sm_ctr) (void)hipFree(c->d_sm_ctr);
   host_pipe_free(c);
+  free_ctg(c);
   bk_free(c, false);
   shard_free(c);
   if (c->d_cb) (void)hipFree(c->d_cb);
@@ -485,6 +502,7 @@ extern "C" int kc_reset(kc_ctx *c, int new_k) {
   HIPCHK(hipStreamSynchronize(c->stream));
   const int old_nl = c->nl, old_k = c->k;
   if (kc_record_longs(new_k) != old_nl) free_results(c);  // else the result arrays are reused by the next finalize
+  free_ctg(c);  // a contig pass belongs to one pass over the reads
   c->out_n = 0;
   c->k = new_k;
   c->cfg.kmer_len = new_k;
@@ -1241,8 +1259,10 @@ static void host_pipe_free(kc_ctx *c) {
     if (h.h_offs[s]) (void)hipHostFree(h.h_offs[s]);
     if (h.copied[s]) (void)hipEventDestroy(h.copied[s]);
     if (h.consumed[s]) (void)hipEventDestroy(h.consumed[s]);
+    if (h.half[s]) (void)hipEventDestroy(h.half[s]);
   }
   if (h.copy_stream) (void)hipStreamDestroy(h.copy_stream);
+  if (h.copy_stream2) (void)hipStreamDestroy(h.copy_stream2);
   memset(&h, 0, sizeof(h));
 }
 
@@ -1251,9 +1271,11 @@ static int host_pipe_init(kc_ctx *c, size_t bytes, size_t reads, bool pinned_sou
   if (h.ready && h.cap_bytes >= bytes && h.cap_reads >= reads && (pinned_source || h.h_bases[0])) return KC_OK;
   host_pipe_free(c);
   HIPCHK(hipStreamCreateWithFlags(&h.copy_stream, hipStreamNonBlocking));
+  HIPCHK(hipStreamCreateWithFlags(&h.copy_stream2, hipStreamNonBlocking));
   for (int s = 0; s < 2; s++) {
-    HIPCHK(hipMalloc((void **)&h.d_bases[s], bytes + 64));
-    HIPCHK(hipMalloc((void **)&h.d_quals[s], bytes + 64));
+    HIPCHK(hipEventCreateWithFlags(&h.half[s], hipEventDisableTiming));
+    HIPCHK(hipMalloc((void **)&h.d_bases[s], bytes + 4096 + 64));  // (+ a page: copies start page-aligned in the source)
+    HIPCHK(hipMalloc((void **)&h.d_quals[s], bytes + 4096 + 64));
     HIPCHK(hipMalloc((void **)&h.d_offs[s], (reads + 1) * 8));
     HIPCHK(hipHostMalloc((void **)&h.h_offs[s], (reads + 1) * 8, hipHostMallocDefault));
     if (!pinned_source) {
@@ -1295,37 +1317,52 @@ static void parallel_copy(uint8_t *dst, const uint8_t *src, size_t n) {
   for (auto &t : th) t.join();
 }
 
+// a block's offsets, copied as the caller holds them, made relative to the block's first byte
+__global__ void kc_rebase_offsets_kernel(uint64_t *offs, uint64_t n, uint64_t base) {
+  const uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i < n) offs[i] -= base;
+}
+
 static int submit_host_reads(kc_ctx *c, const uint8_t *bases, const uint8_t *quals, const uint64_t *offsets, uint64_t nreads, int mode,
                              uint64_t *d_records, uint64_t seg_capacity, int fmt) {
   const size_t HOST_BLOCK = host_block_bytes();
   const bool with_quals = fmt == FMT_READS;
   const bool pinned = is_pinned_host(bases) && (!with_quals || is_pinned_host(quals));
-  // blocks of whole reads: at most HOST_BLOCK bytes, and a single read that is longer gets a block of its own
+  if (getenv("KC_DEBUG_ADDR")) {
+    hipPointerAttribute_t at;
+    memset(&at, 0, sizeof(at));
+    const hipError_t e = hipPointerGetAttributes(&at, bases);
+    (void)hipGetLastError();
+    fprintf(stderr, "kc host input: %p pinned=%d (hipPointerGetAttributes: %s, type %d, device %d)\n", (const void *)bases, (int)pinned,
+            hipGetErrorString(e), (int)at.type, at.device);
+  }
+  // blocks of whole reads: at most HOST_BLOCK bytes, and a single read that is longer gets a block of its own.  The end
+  // of a block is found by bisection (the offsets only grow): walking the reads one by one, as round 2 did, cost the host
+  // more per block than the copy took -- with the loop that rebased the offsets it made the pipe CPU-bound (47 GB/s over
+  // a link that does 57)
+  struct Blk { uint64_t r0, r1; };
+  auto next_block = [&](uint64_t r0) {
+    const uint64_t limit = offsets[r0] + HOST_BLOCK;
+    uint64_t r1 = (uint64_t)(std::upper_bound(offsets + r0 + 1, offsets + nreads + 1, limit) - offsets) - 1;  // last r1 with offsets[r1] <= limit
+    if (r1 <= r0) r1 = r0 + 1;
+    return Blk{r0, r1};
+  };
   size_t max_bytes = 0, max_reads = 0;
-  {
-    uint64_t r0 = 0;
-    while (r0 < nreads) {
-      uint64_t r1 = r0 + 1;
-      while (r1 < nreads && offsets[r1 + 1] - offsets[r0] <= HOST_BLOCK) r1++;
-      max_bytes = std::max<size_t>(max_bytes, (size_t)(offsets[r1] - offsets[r0]));
-      max_reads = std::max<size_t>(max_reads, (size_t)(r1 - r0));
-      r0 = r1;
-    }
+  for (uint64_t r0 = 0; r0 < nreads;) {
+    const Blk b = next_block(r0);
+    max_bytes = std::max<size_t>(max_bytes, (size_t)(offsets[b.r1] - offsets[b.r0]));
+    max_reads = std::max<size_t>(max_reads, (size_t)(b.r1 - b.r0));
+    r0 = b.r1;
   }
   int rc = host_pipe_init(c, max_bytes, max_reads, pinned);
   if (rc) return rc;
   auto &h = c->hp;
-  struct Blk { uint64_t r0, r1; };
-  auto next_block = [&](uint64_t r0) {
-    uint64_t r1 = r0 + 1;
-    while (r1 < nreads && offsets[r1 + 1] - offsets[r0] <= HOST_BLOCK) r1++;
-    return Blk{r0, r1};
-  };
   // stage: host side of one block + its copies (asynchronous, on the copy stream)
   auto stage = [&](int s, const Blk &b) -> int {
     if (h.used[s]) HIPCHK(hipEventSynchronize(h.consumed[s]));  // the kernels of two blocks ago have read slot s
     const uint64_t nb = offsets[b.r1] - offsets[b.r0], nr = b.r1 - b.r0;
-    for (uint64_t i = 0; i <= nr; i++) h.h_offs[s][i] = offsets[b.r0 + i] - offsets[b.r0];
+    // the block's offsets as they are (a plain copy, a few threads); the device makes them relative to the block
+    parallel_copy(reinterpret_cast<uint8_t *>(h.h_offs[s]), reinterpret_cast<const uint8_t *>(offsets + b.r0), (nr + 1) * 8);
     const uint8_t *sb = bases + offsets[b.r0], *sq = with_quals ? quals + offsets[b.r0] : nullptr;
     if (!pinned) {
       parallel_copy(h.h_bases[s], sb, nb);
@@ -1335,9 +1372,31 @@ static int submit_host_reads(kc_ctx *c, const uint8_t *bases, const uint8_t *qua
         sq = h.h_quals[s];
       }
     }
-    HIPCHK(hipMemcpyAsync(h.d_bases[s], sb, nb, hipMemcpyHostToDevice, h.copy_stream));
-    if (with_quals) HIPCHK(hipMemcpyAsync(h.d_quals[s], sq, nb, hipMemcpyHostToDevice, h.copy_stream));
+    // two copies at a time, on two streams (one copy alone reached 46-50 GB/s of the link's 63): bases and qualities,
+    // or the two halves of a block without qualities (the read cache's bytes)
+    // A copy whose source starts on a page boundary runs at the link's rate (57 GB/s measured), one that starts at an
+    // arbitrary byte -- a block starts where a read starts -- at 47: start every copy at the page boundary below (the
+    // bytes in front belong to the caller's same buffer, `lead` of them, skipped on the device)
+    auto lead_of = [&](const uint8_t *p, const uint8_t *buffer_start) -> uint32_t {
+      const uint32_t l = (uint32_t)((uintptr_t)p & 4095u);
+      return (size_t)(p - buffer_start) >= l ? l : 0u;
+    };
+    h.lead_b[s] = lead_of(sb, pinned ? bases : h.h_bases[s]);
+    h.lead_q[s] = with_quals ? lead_of(sq, pinned ? quals : h.h_quals[s]) : 0u;
+    if (with_quals) {
+      HIPCHK(hipMemcpyAsync(h.d_bases[s], sb - h.lead_b[s], nb + h.lead_b[s], hipMemcpyHostToDevice, h.copy_stream));
+      HIPCHK(hipMemcpyAsync(h.d_quals[s], sq - h.lead_q[s], nb + h.lead_q[s], hipMemcpyHostToDevice, h.copy_stream2));
+    } else {
+      const uint64_t tot = nb + h.lead_b[s], h1 = (tot / 2) & ~(uint64_t)4095;
+      const uint8_t *src = sb - h.lead_b[s];
+      if (h1) HIPCHK(hipMemcpyAsync(h.d_bases[s], src, h1, hipMemcpyHostToDevice, h.copy_stream));
+      HIPCHK(hipMemcpyAsync(h.d_bases[s] + h1, src + h1, tot - h1, hipMemcpyHostToDevice, h.copy_stream2));
+    }
+    HIPCHK(hipEventRecord(h.half[s], h.copy_stream2));
     HIPCHK(hipMemcpyAsync(h.d_offs[s], h.h_offs[s], (nr + 1) * 8, hipMemcpyHostToDevice, h.copy_stream));
+    hipLaunchKernelGGL(kc_rebase_offsets_kernel, dim3((unsigned)((nr + 256) / 256)), dim3(256), 0, h.copy_stream, h.d_offs[s], nr + 1, offsets[b.r0]);
+    HIPCHK(hipGetLastError());
+    HIPCHK(hipStreamWaitEvent(h.copy_stream, h.half[s], 0));
     HIPCHK(hipEventRecord(h.copied[s], h.copy_stream));
     h.used[s] = true;
     return KC_OK;
@@ -1358,7 +1417,7 @@ static int submit_host_reads(kc_ctx *c, const uint8_t *bases, const uint8_t *qua
     HIPCHK(hipStreamWaitEvent(c->stream, h.copied[s], 0));
     rc = raw_kmer_stats(c, h.d_offs[s], nr, mode);
     if (rc) return rc;
-    rc = run_extract_device(c, h.d_bases[s], h.d_quals[s], h.d_offs[s], nr, nb, mode, fmt, d_records, seg_capacity);
+    rc = run_extract_device(c, h.d_bases[s] + h.lead_b[s], h.d_quals[s] + h.lead_q[s], h.d_offs[s], nr, nb, mode, fmt, d_records, seg_capacity);
     if (rc) return rc;
     HIPCHK(hipEventRecord(h.consumed[s], c->stream));
     c->num_reads += nr;
@@ -1368,6 +1427,7 @@ static int submit_host_reads(kc_ctx *c, const uint8_t *bases, const uint8_t *qua
   }
   // the caller's arrays are free to change once every copy has left them
   HIPCHK(hipStreamSynchronize(h.copy_stream));
+  HIPCHK(hipStreamSynchronize(h.copy_stream2));
   return KC_OK;
 }
 
@@ -2376,6 +2436,8 @@ static int bk_finalize(kc_ctx *c) {
   return table_finalize_append(c);
 }
 
+static int ctg_merge(kc_ctx *c);
+
 extern "C" int kc_finalize(kc_ctx *c, kc_result *out) {
   if (!c) return KC_ERR_INVALID_ARG;
   HIPCHK(hipSetDevice(c->cfg.device));
@@ -2407,6 +2469,10 @@ extern "C" int kc_finalize(kc_ctx *c, kc_result *out) {
     c->purged = c->h_ctrs[CTR_PURGED];
     c->sum_counts = c->h_ctrs[CTR_SUM_COUNTS];
     c->unique_at_finalize = c->h_ctrs[CTR_ENTRIES] + c->h_cb[CB_ENTRIES];
+    if (c->ctg_table.keys) {  // the contig pass: its k-mers join the reads' results (kc_ctg.hpp)
+      rc = ctg_merge(c);
+      if (rc) return rc;
+    }
     if (c->nl != c->nl_ext) {  // k % 32 in {30, 31}: the caller sees the reference's width
       if (c->d_out_keys_ext) HIPCHK(hipFree(c->d_out_keys_ext));
       c->d_out_keys_ext = nullptr;
@@ -2672,7 +2738,7 @@ extern "C" int kc_set_tuning(kc_ctx *c, const kc_tuning *t) {
 }
 
 template <int NL>
-static int lookup_t(kc_ctx *c, const uint64_t *dq, uint64_t nq, uint16_t *dc, uint8_t *dl, uint8_t *dr) {
+static int ensure_index(kc_ctx *c) {
   if (!c->d_index) {
     if (c->out_n >= 0xFFFFFFFFull) {
       snprintf(g_last_error, sizeof(g_last_error), "the lookup index holds at most 2^32 - 1 results");
@@ -2689,6 +2755,13 @@ static int lookup_t(kc_ctx *c, const uint64_t *dq, uint64_t nq, uint16_t *dc, ui
       HIPCHK(hipGetLastError());
     }
   }
+  return KC_OK;
+}
+
+template <int NL>
+static int lookup_t(kc_ctx *c, const uint64_t *dq, uint64_t nq, uint16_t *dc, uint8_t *dl, uint8_t *dr) {
+  int rc = ensure_index<NL>(c);
+  if (rc) return rc;
   if (nq) {
     hipLaunchKernelGGL(kc_lookup_kernel<NL>, dim3((unsigned)((nq + 255) / 256)), dim3(256), 0, c->stream, dq, nq, c->k, c->d_index,
                        c->index_cap - 1, c->d_out_keys, c->d_out_counts, c->d_out_left, c->d_out_right, dc, dl, dr);
@@ -2740,6 +2813,111 @@ extern "C" int kc_lookup(kc_ctx *c, const uint64_t *queries, uint64_t nq, int on
   }
   if (sq) (void)hipFree(sq);
   return rc;
+}
+
+// ---- the contig pass (kc_ctg.hpp) ----------------------------------------------------------------------------------
+extern "C" int kc_begin_ctg_kmers(kc_ctx *c, uint64_t max_ctg_kmers) {
+  if (!c) return KC_ERR_INVALID_ARG;
+  if (c->finalized) return KC_ERR_STATE;
+  HIPCHK(hipSetDevice(c->cfg.device));
+  free_ctg(c);
+  const uint64_t cap = next_pow2(std::max<uint64_t>(1024, 2 * max_ctg_kmers));
+  HIPCHK(hipMalloc((void **)&c->ctg_table.keys, cap * (size_t)c->nl * 8));
+  HIPCHK(hipMalloc((void **)&c->ctg_table.vals, cap * 2 * 4));
+  HIPCHK(hipMalloc((void **)&c->d_ctg_status, 4 * 8));
+  HIPCHK(hipMemsetAsync(c->ctg_table.keys, 0xFF, cap * (size_t)c->nl * 8, c->stream));
+  HIPCHK(hipMemsetAsync(c->ctg_table.vals, 0, cap * 2 * 4, c->stream));
+  HIPCHK(hipMemsetAsync(c->d_ctg_status, 0, 4 * 8, c->stream));
+  c->ctg_table.mask = cap - 1;
+  c->ctg_cap = cap;
+  return KC_OK;
+}
+
+extern "C" int kc_submit_ctg_block(kc_ctx *c, const char *seqs, const uint16_t *depths, uint64_t len, int on_device) {
+  if (!c || (len && (!seqs || !depths))) return KC_ERR_INVALID_ARG;
+  if (c->finalized || !c->ctg_table.keys) return KC_ERR_STATE;  // kc_begin_ctg_kmers first
+  if (!len) return KC_OK;
+  HIPCHK(hipSetDevice(c->cfg.device));
+  const uint8_t *d_seqs = reinterpret_cast<const uint8_t *>(seqs);
+  const uint16_t *d_depths = depths;
+  uint8_t *tmp = nullptr;
+  if (!on_device) {
+    HIPCHK(hipMalloc((void **)&tmp, len * 3 + 16));
+    HIPCHK(hipMemcpyAsync(tmp, seqs, len, hipMemcpyHostToDevice, c->stream));
+    uint16_t *td = reinterpret_cast<uint16_t *>(tmp + ((len + 15) & ~(uint64_t)15));
+    HIPCHK(hipMemcpyAsync(td, depths, len * 2, hipMemcpyHostToDevice, c->stream));
+    d_seqs = tmp;
+    d_depths = td;
+  }
+  const unsigned nblk = (unsigned)((len + 255) / 256);
+  switch (c->nl) {
+    case 1: hipLaunchKernelGGL(kc_ctg_insert_kernel<1>, dim3(nblk), dim3(256), 0, c->stream, d_seqs, d_depths, len, c->k, c->ctg_table, c->d_ctg_status); break;
+    case 2: hipLaunchKernelGGL(kc_ctg_insert_kernel<2>, dim3(nblk), dim3(256), 0, c->stream, d_seqs, d_depths, len, c->k, c->ctg_table, c->d_ctg_status); break;
+    case 3: hipLaunchKernelGGL(kc_ctg_insert_kernel<3>, dim3(nblk), dim3(256), 0, c->stream, d_seqs, d_depths, len, c->k, c->ctg_table, c->d_ctg_status); break;
+    default: hipLaunchKernelGGL(kc_ctg_insert_kernel<4>, dim3(nblk), dim3(256), 0, c->stream, d_seqs, d_depths, len, c->k, c->ctg_table, c->d_ctg_status); break;
+  }
+  c->num_gpu_calls++;
+  hipError_t e = hipGetLastError();
+  uint64_t st[2] = {0, 0};
+  if (e == hipSuccess) e = hipMemcpyAsync(st, c->d_ctg_status, 16, hipMemcpyDeviceToHost, c->stream);
+  if (e == hipSuccess) e = hipStreamSynchronize(c->stream);
+  if (tmp) (void)hipFree(tmp);
+  if (e != hipSuccess) return hip_fail(e, "kc_submit_ctg_block", __LINE__);
+  if (st[0]) return KC_ERR_BAD_BASE;
+  c->ctg_attempted += len;
+  c->ctg_new = st[1];
+  if (st[1] * 4 > c->ctg_cap * 3) {
+    snprintf(g_last_error, sizeof(g_last_error), "contig pass: %llu distinct k-mers overfill the table kc_begin_ctg_kmers made (%llu slots)",
+             (unsigned long long)st[1], (unsigned long long)c->ctg_cap);
+    return KC_ERR_CAPACITY;
+  }
+  return KC_OK;
+}
+
+template <int NL>
+static int ctg_merge_t(kc_ctx *c) {
+  int rc = ensure_index<NL>(c);  // over the reads' results
+  if (rc) return rc;
+  const uint64_t n_res = c->out_n;
+  uint64_t *cur = c->d_ctg_status + 2;  // [2] cursor, [3] sum of the appended counts
+  const unsigned nblk = (unsigned)((c->ctg_cap + 255) / 256);
+  for (int pass = 0; pass < 2; pass++) {
+    uint64_t init[2] = {n_res, 0};
+    HIPCHK(hipMemcpyAsync(cur, init, 16, hipMemcpyHostToDevice, c->stream));
+    hipLaunchKernelGGL(kc_ctg_merge_kernel<NL>, dim3(nblk), dim3(256), 0, c->stream, c->ctg_table, c->ctg_cap, c->d_index, c->index_cap - 1, n_res,
+                       c->d_out_keys, c->d_out_counts, c->d_out_left, c->d_out_right, pass == 0 ? (uint64_t)0 : c->out_cap, NL, cur, cur + 1);
+    c->num_gpu_calls++;
+    HIPCHK(hipGetLastError());
+    uint64_t got[2];
+    HIPCHK(hipMemcpyAsync(got, cur, 16, hipMemcpyDeviceToHost, c->stream));
+    HIPCHK(hipStreamSynchronize(c->stream));
+    if (pass == 0) {
+      if (got[0] == n_res) return KC_OK;  // nothing to add
+      // (the index stays valid: it points at the first n_res entries, which keep their places)
+      uint32_t *index = c->d_index;
+      const uint64_t icap = c->index_cap;
+      c->d_index = nullptr;
+      rc = grow_results(c, got[0], n_res);
+      c->d_index = index;
+      c->index_cap = icap;
+      if (rc) return rc;
+      c->out_n = n_res;
+    } else {
+      c->out_n = got[0];
+      c->sum_counts += got[1];
+    }
+  }
+  free_index(c);  // the results have changed: a later kc_lookup builds it again
+  return KC_OK;
+}
+
+static int ctg_merge(kc_ctx *c) {
+  switch (c->nl) {
+    case 1: return ctg_merge_t<1>(c);
+    case 2: return ctg_merge_t<2>(c);
+    case 3: return ctg_merge_t<3>(c);
+    default: return ctg_merge_t<4>(c);
+  }
 }
 
 extern "C" int kc_get_kernel_times(kc_ctx *c, kc_kernel_time *out, int max, int *n) {

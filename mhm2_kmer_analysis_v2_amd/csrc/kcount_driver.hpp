@@ -209,6 +209,21 @@ class HashTableDriver {
   uint64_t final_capacity = 0;
   double t_insert = 0;
 
+  std::string ctg_seqs;               // contig pass: the supermers as characters, '_'-joined ...
+  std::vector<uint16_t> ctg_depths;   // ... and the depth of every character's contig
+  InsertStats ctg_stats;
+
+  void flush_ctg_block() {
+    if (ctg_seqs.empty()) return;
+    StopWatch sw;
+    check(kc_submit_ctg_block(ctx, ctg_seqs.data(), ctg_depths.data(), ctg_seqs.size(), 0), "kc_submit_ctg_block");
+    num_gpu_calls++;
+    ctg_stats.new_inserts += ctg_seqs.size();
+    ctg_seqs.clear();
+    ctg_depths.clear();
+    t_insert += sw.stop();
+  }
+
   void flush_block() {
     StopWatch sw;
     if (!elem_buff.empty()) {
@@ -241,7 +256,8 @@ class HashTableDriver {
   HashTableDriver(HashTableDriver &&o) noexcept
       : ctx(o.ctx), kmer_len(o.kmer_len), elem_buff(std::move(o.elem_buff)), packed_buff(std::move(o.packed_buff)),
         output_keys(std::move(o.output_keys)), output_vals(std::move(o.output_vals)), output_index(o.output_index), stats(o.stats),
-        num_gpu_calls(o.num_gpu_calls), final_capacity(o.final_capacity), t_insert(o.t_insert), pass_type(o.pass_type) {
+        num_gpu_calls(o.num_gpu_calls), final_capacity(o.final_capacity), t_insert(o.t_insert), ctg_seqs(std::move(o.ctg_seqs)),
+        ctg_depths(std::move(o.ctg_depths)), ctg_stats(o.ctg_stats), pass_type(o.pass_type) {
     o.ctx = nullptr;
   }
 
@@ -290,7 +306,13 @@ class HashTableDriver {
     msgs += "kcount_mi355: k=" + std::to_string(kmer_len) + " words=" + std::to_string(N_LONGS) + ", k-mer buffer for " +
             std::to_string(buffered) + " occurrences (" + std::to_string((uint64_t)((double)buffered * per_kmer / 1e6)) + " MB)\n";
   }
-  void init_ctg_kmers(uint64_t, size_t) {}  // contig pass: dead in the proxy (F8 in SURVEY.md)
+  // gpu_hash_table.hpp:158: from here on insert_supermer carries contig k-mers with the contig's depth as their count
+  // (insert_supermer_from_ctg, kcount_cpu.cpp:357-407).  Dead in the proxy, complete here: csrc/kc_ctg.hpp.
+  void init_ctg_kmers(uint64_t max_elems, size_t /*gpu_avail_mem*/) {
+    flush_block();
+    pass_type = CTG_KMERS_PASS;
+    check(kc_begin_ctg_kmers(ctx, max_elems), "kc_begin_ctg_kmers");
+  }
 
   // gpu_hash_table.cpp:681-695: one 4-bit packed supermer as kcount_gpu.cpp:153-161 cuts it (odd nibbles masked to 0);
   // the bytes are joined by '_' exactly like the reference's elem_buff_host and unpacked on the device
@@ -299,6 +321,20 @@ class HashTableDriver {
   // kcount_gpu.cpp:160 turns it into 1); a larger count is submitted as that many copies, which saturate exactly like
   // the reference's min(count + n, 65535) chain does.
   void insert_supermer(const std::string &packed, count_t supermer_count) {
+    if (pass_type == CTG_KMERS_PASS) {
+      // back to characters (the nibble codes of parse_and_pack.cpp:196-213), every one with the supermer's count as its
+      // depth: the block kc_submit_ctg_block takes
+      static const char to_base[16] = {'_', 'a', 'c', 'g', 't', 'A', 'C', 'G', 'T', 'N', '_', '_', '_', '_', '_', '_'};
+      if (ctg_seqs.size() + 2 * packed.size() + 1 >= HASHTABLE_BLOCK_SIZE) flush_ctg_block();
+      for (unsigned char b : packed) {
+        ctg_seqs += to_base[b >> 4];
+        ctg_seqs += to_base[b & 15];
+      }
+      ctg_seqs += '_';
+      ctg_depths.resize(ctg_seqs.size(), (uint16_t)(supermer_count > 65535 ? 65535 : supermer_count));
+      ctg_stats.attempted++;
+      return;
+    }
     const count_t copies = supermer_count ? supermer_count : 1;
     for (count_t c = 0; c < copies; c++) {
       if (packed_buff.size() + packed.size() + 1 >= HASHTABLE_BLOCK_SIZE) flush_block();
@@ -323,13 +359,21 @@ class HashTableDriver {
   }
   void flush_inserts() {
     flush_block();
+    flush_ctg_block();
     check(kc_flush(ctx), "kc_flush");
   }
-  void done_ctg_kmer_inserts(uint64_t &attempted, uint64_t &dropped, uint64_t &new_inserts) { attempted = dropped = new_inserts = 0; }
+  // gpu_hash_table.cpp:697-734: the contig k-mers are in (they join the results in done_all_inserts)
+  void done_ctg_kmer_inserts(uint64_t &attempted, uint64_t &dropped, uint64_t &new_inserts) {
+    flush_ctg_block();
+    attempted = ctg_stats.attempted;
+    dropped = 0;
+    new_inserts = ctg_stats.new_inserts;
+  }
 
   // gpu_hash_table.cpp:736-784: purge + compact + copy back
   void done_all_inserts(uint64_t &num_dropped, uint64_t &num_unique, uint64_t &num_purged) {
     flush_block();
+    flush_ctg_block();
     kc_result r;
     check(kc_finalize(ctx, &r), "kc_finalize");
     kc_stats st;

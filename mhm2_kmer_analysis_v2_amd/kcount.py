@@ -172,6 +172,21 @@ class KmerCounter:
         out = out[:n.value]
         return out["target"].copy(), out["offset"].copy(), out["len"].copy(), nk.value, packed
 
+    def begin_ctg_kmers(self, max_ctg_kmers):
+        """HashTableInserter::init_ctg_kmers: room for that many distinct contig k-mers (before finalize)."""
+        check(lib().kc_begin_ctg_kmers(self._h, int(max_ctg_kmers)), "kc_begin_ctg_kmers")
+
+    def submit_ctgs(self, ctgs, depths):
+        """process_seq(ctg.seq, ctg.depth) for every contig: a '_'-joined block with its per-character depths."""
+        block = b"_".join(c.encode() if isinstance(c, str) else c for c in ctgs) + b"_"
+        dd = np.zeros(len(block), dtype=np.uint16)
+        at = 0
+        for c, d in zip(ctgs, depths):
+            dd[at:at + len(c) + 1] = d
+            at += len(c) + 1
+        blk = np.frombuffer(block, dtype=np.uint8)
+        check(lib().kc_submit_ctg_block(self._h, blk.ctypes.data, dd.ctypes.data, len(blk), 0), "kc_submit_ctg_block")
+
     def submit_packed_supermers(self, packed):
         """4-bit packed supermers joined by the byte '_' (HashTableGPUDriver::insert_supermer's buffer)."""
         pp, dev = _ptr(packed)

@@ -62,6 +62,8 @@ def lib():
         L.orc_add_reads.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_uint64]
         L.orc_insert_supermer.restype = C.c_int
         L.orc_insert_supermer.argtypes = [C.c_void_p, C.c_int, C.c_char_p, C.c_int]
+        L.orc_add_ctg.restype = C.c_int
+        L.orc_add_ctg.argtypes = [C.c_void_p, C.c_char_p, C.c_int, C.c_int]
         L.orc_build_supermers.restype = C.c_int
         L.orc_build_supermers.argtypes = [C.c_void_p, C.c_char_p, C.c_int, C.c_void_p, C.c_void_p, C.c_void_p]
         L.orc_finalize.restype = C.c_int
@@ -170,6 +172,13 @@ class Oracle:
             rc = lib().orc_add_reads(self._h, bases.ctypes.data, quals.ctypes.data, off.ctypes.data, r1 - r0)
             if rc:
                 raise RuntimeError("orc_add_reads failed: %d" % rc)
+
+    def add_ctg(self, seq, depth):
+        """The contig pass (after every read): process_seq(seq, depth) + insert_supermer_from_ctg (kcount_cpu.cpp:357-407)."""
+        b = seq.encode() if isinstance(seq, str) else seq
+        rc = lib().orc_add_ctg(self._h, b, len(b), int(depth))
+        if rc:
+            raise RuntimeError("orc_add_ctg failed: %d" % rc)
 
     def insert_supermer(self, target, seq):
         b = seq.encode() if isinstance(seq, str) else seq

@@ -623,6 +623,102 @@ int orc_add_reads(orc_ctx *c, const char *bases, const char *quals, const uint64
   return err;
 }
 
+/* ------------------------------------------------------------------ */
+/* the contig pass (dead in the proxy, SURVEY.md F8: add_ctg_kmers is commented out at kcount.cpp:106-139, but the
+ * backend code is there): HashTableInserter::init_ctg_kmers (kcount_cpu.cpp:472-475) switches insert_supermer to
+ * insert_supermer_from_ctg (kcount_cpu.cpp:357-407).  A contig's k-mers come with the contig's depth as their count
+ * (kcount.cpp:129, Supermer::count, get_kmers_and_exts kcount_cpu.cpp:308-336).                                      */
+/* ------------------------------------------------------------------ */
+static void vals_set_from_ctg(orc_vals *v, char left, char right, int count) {
+  memset(v, 0, sizeof(*v));
+  v->count = (uint16_t)count;
+  v->from_ctg = 1;
+  /* ExtCounts::inc(ext, count), kcount_cpu.cpp:157-164 */
+  int li = left == 'A' ? 0 : left == 'C' ? 1 : left == 'G' ? 2 : left == 'T' ? 3 : -1;
+  int ri = right == 'A' ? 0 : right == 'C' ? 1 : right == 'G' ? 2 : right == 'T' ? 3 : -1;
+  if (li >= 0) v->left[li] = (uint16_t)count;
+  if (ri >= 0) v->right[ri] = (uint16_t)count;
+}
+
+/* insert_supermer_from_ctg, kcount_cpu.cpp:357-407, statement for statement */
+static int insert_supermer_ctg(orc_ctx *c, orc_table *t, const char *sm, int len, int depth, char *up, uint64_t *kbuf) {
+  int k = c->k, nl = c->nl;
+  for (int i = 0; i < len; i++) {
+    char b = sm[i];
+    if (b >= 'a' && b <= 'z') b += 'A' - 'a';
+    if (b != 'A' && b != 'C' && b != 'G' && b != 'T' && b != 'N') return -2;
+    up[i] = b;
+  }
+  orc_get_kmers(up, len, k, kbuf);
+  uint64_t rc[ORC_MAX_LONGS];
+  for (int i = 1; i < len - k; i++) {
+    const uint64_t *km = kbuf + (size_t)i * nl;
+    char left = up[i - 1];
+    if (!(sm[i - 1] >= 'A' && sm[i - 1] <= 'Z')) left = '0';
+    char right = up[i + k];
+    if (!(sm[i + k] >= 'A' && sm[i + k] <= 'Z')) right = '0';
+    orc_revcomp(km, k, rc);
+    if (orc_kmer_less(rc, km, nl)) {
+      km = rc;
+      char tl = left;
+      left = comp_nucleotide(right);
+      right = comp_nucleotide(tl);
+    }
+    if ((double)(t->num_elems + 1) > 0.66 * (double)t->capacity)
+      if (table_grow(t, nl)) return -1;
+    uint64_t before = t->num_elems;
+    orc_vals *v = table_insert(t, km, nl);
+    while (!v) {
+      if (table_grow(t, nl)) return -1;
+      before = t->num_elems;
+      v = table_insert(t, km, nl);
+    }
+    int is_new = t->num_elems != before;
+    int count = depth;
+    int insert_it = 0;
+    if (is_new) {
+      insert_it = 1;
+    } else if (!v->from_ctg) {
+      /* existing entry is from a read */
+      if (v->count == 1) {
+        insert_it = 1; /* singleton read k-mer: would be purged anyway */
+      } else {
+        char le = orc_get_ext(v->left, v->count, c->dmin_thres), re = orc_get_ext(v->right, v->count, c->dmin_thres);
+        if (le == 'X' || le == 'F' || re == 'X' || re == 'F') insert_it = 1; /* non-UU: replace */
+      }
+    } else {
+      /* existing entry from a contig */
+      if (v->count) {
+        insert_it = 1;
+        char le = orc_get_ext(v->left, v->count, c->dmin_thres), re = orc_get_ext(v->right, v->count, c->dmin_thres);
+        if (le != left || re != right) count = 0;                 /* two contig k-mers disagree: set up to purge */
+        else count = count < v->count ? count : v->count;         /* the same k-mer from several contigs: not counted again */
+      }
+    }
+    if (insert_it) vals_set_from_ctg(v, left, right, count);
+  }
+  return 0;
+}
+
+/* One contig through SeqBlockInserter::process_seq(seq, depth) + the exchange + insert_supermer in the contig pass.
+ * Call after every read has been added.  Returns 0, -1 (memory), -2 (bad character). */
+int orc_add_ctg(orc_ctx *c, const char *seq, int len, int depth) {
+  if (len < c->k + 2) return 0; /* kcount.cpp:127 */
+  uint64_t *kbuf = (uint64_t *)malloc(((size_t)len + 1) * 8 * c->nl);
+  int *tr = (int *)malloc(3 * (size_t)len * sizeof(int));
+  char *up = (char *)malloc((size_t)len + 1);
+  int err = (!kbuf || !tr || !up) ? -1 : 0;
+  if (!err) {
+    int n = supermers_of(c, seq, len, kbuf, tr, tr + len, tr + 2 * len);
+    for (int i = 0; i < n && !err; i++)
+      err = insert_supermer_ctg(c, &c->tables[tr[i]], seq + tr[len + i], tr[2 * len + i], depth, up, kbuf);
+  }
+  free(kbuf);
+  free(tr);
+  free(up);
+  return err;
+}
+
 /* Receiver entry on its own (what the RPC callback calls, kmer_dht.cpp:147-151):
  * one ASCII supermer, case = quality, straight into rank `target`'s table. */
 int orc_insert_supermer(orc_ctx *c, int target, const char *sm, int len) {

@@ -16,14 +16,14 @@
 
 enum { OP_ADD, OP_XOR, OP_LSHL, OP_LSHL_ADD, OP_AND_OR, OP_OR3, OP_ALIGNBIT, OP_BFE, OP_CNDMASK, OP_MUL24, OP_MAD24, OP_MULLO, OP_MULHI,
        OP_LSHL64, OP_LSHR64, OP_ADD64, OP_CMP, OP_PERM, OP_DPP, OP_MOV, OP_MAD64_32,
-       OP_CND_S, OP_CMP_CND, OP_AND, OP_OR, OP_SUB, OP_MIN, OP_LSHR_V, OP_BFI, OP_ADD_S, OP_ADD_LIT, OP_BITOP3, OP_ADD3, OP_LSHL_OR, OP_SDWA, OP_MAD24_S, OP_CMP64, OP_READLANE, OP_COUNT };
+       OP_CND_S, OP_CMP_CND, OP_AND, OP_OR, OP_SUB, OP_MIN, OP_LSHR_V, OP_BFI, OP_ADD_S, OP_ADD_LIT, OP_BITOP3, OP_ADD3, OP_LSHL_OR, OP_SDWA, OP_MAD24_S, OP_CMP64, OP_READLANE, OP_SALU, OP_SALU64, OP_SALU_VALU, OP_COUNT };
 static const char *op_name[OP_COUNT] = {"v_add_u32", "v_xor_b32", "v_lshlrev_b32", "v_lshl_add_u32", "v_and_or_b32", "v_or3_b32", "v_alignbit_b32",
                                         "v_bfe_u32", "v_cndmask_b32", "v_mul_u32_u24", "v_mad_u32_u24", "v_mul_lo_u32", "v_mul_hi_u32",
                                         "v_lshlrev_b64", "v_lshrrev_b64", "v_add_co+v_addc (2 instr)", "v_cmp_lt_u32 (->vcc)", "v_perm_b32",
                                         "v_mov_b32 dpp row_shr:1", "v_mov_b32", "v_mad_u64_u32",
                                         "v_cndmask_b32_e64 (sgpr pair)", "v_cmp_lt_u32+v_cndmask (2 instr)", "v_and_b32", "v_or_b32", "v_sub_u32", "v_min_u32",
                                         "v_lshrrev_b32 (vgpr amount)", "v_bfi_b32", "v_add_u32 (sgpr operand)", "v_add_u32 (32-bit literal)", "v_bitop3_b32",
-                                        "v_add3_u32", "v_lshl_or_b32", "v_add_u32_sdwa", "v_mad_u32_u24 (sgpr operand)", "v_cmp_lt_u64 (->vcc)", "v_readlane_b32"};
+                                        "v_add3_u32", "v_lshl_or_b32", "v_add_u32_sdwa", "v_mad_u32_u24 (sgpr operand)", "v_cmp_lt_u64 (->vcc)", "v_readlane_b32", "s_add_u32", "s_and_b64", "s_add_u32 + v_add_u32 (2 instr)"};
 
 template <int OP>
 __global__ __launch_bounds__(1024) void k(uint32_t *out, unsigned long long *stamps, int iters) {
@@ -37,6 +37,12 @@ __global__ __launch_bounds__(1024) void k(uint32_t *out, unsigned long long *sta
   uint32_t c = threadIdx.x & 31u;
   uint64_t sm = __ballot((threadIdx.x & 3) == 1);
   uint32_t ss = __builtin_amdgcn_readfirstlane(threadIdx.x) | 5u;
+  uint32_t sr[8];
+  uint64_t sq[8];
+  for (int i = 0; i < 8; i++) {
+    sr[i] = __builtin_amdgcn_readfirstlane(threadIdx.x * 7 + i);
+    sq[i] = __ballot((threadIdx.x + i) & 1);
+  }
   __syncthreads();
   const unsigned long long t0 = __builtin_amdgcn_s_memtime(), w0 = __builtin_amdgcn_s_memrealtime();
   for (int it = 0; it < iters; it++) {
@@ -80,7 +86,10 @@ __global__ __launch_bounds__(1024) void k(uint32_t *out, unsigned long long *sta
   if (OP == OP_SDWA) asm volatile("v_add_u32_sdwa %0, %0, %1 dst_sel:DWORD dst_unused:UNUSED_PAD src0_sel:DWORD src1_sel:WORD_1" : "+v"(r[i]) : "v"(r[j])); \
   if (OP == OP_MAD24_S) asm volatile("v_mad_u32_u24 %0, %0, %2, %1" : "+v"(r[i]) : "v"(r[j]), "s"(ss));                                            \
   if (OP == OP_CMP64) asm volatile("v_cmp_lt_u64 vcc, %0, %1" : : "v"(q[i]), "v"(q[j]) : "vcc");                                                   \
-  if (OP == OP_READLANE) asm volatile("v_readlane_b32 %0, %1, 3" : "=s"(ss) : "v"(r[i]));
+  if (OP == OP_READLANE) asm volatile("v_readlane_b32 %0, %1, 3" : "=s"(ss) : "v"(r[i]));                                                          \
+  if (OP == OP_SALU) asm volatile("s_add_u32 %0, %0, %1" : "+s"(sr[i]) : "s"(sr[j]) : "scc");                                                      \
+  if (OP == OP_SALU64) asm volatile("s_and_b64 %0, %0, %1" : "+s"(sq[i]) : "s"(sq[j]) : "scc");                                                    \
+  if (OP == OP_SALU_VALU) asm volatile("s_add_u32 %0, %0, %2\n\tv_add_u32 %1, %1, %3" : "+s"(sr[i]), "+v"(r[i]) : "s"(sr[j]), "v"(r[j]) : "scc");
       REP8(A)
 #undef A
     }
@@ -88,7 +97,7 @@ __global__ __launch_bounds__(1024) void k(uint32_t *out, unsigned long long *sta
   const unsigned long long t1 = __builtin_amdgcn_s_memtime(), w1 = __builtin_amdgcn_s_memrealtime();
   uint32_t acc = 0;
   for (int i = 0; i < 8; i++) acc += r[i] + (uint32_t)q[i] + (uint32_t)(q[i] >> 32);
-  out[blockIdx.x * blockDim.x + threadIdx.x] = acc + lds[threadIdx.x & 15] + ss;
+  out[blockIdx.x * blockDim.x + threadIdx.x] = acc + lds[threadIdx.x & 15] + ss + sr[0] + sr[1] + sr[2] + sr[3] + sr[4] + sr[5] + sr[6] + sr[7] + (uint32_t)(sq[0] ^ sq[1] ^ sq[2] ^ sq[3] ^ sq[4] ^ sq[5] ^ sq[6] ^ sq[7]);
   if ((threadIdx.x & 63) == 0) {
     const size_t w = ((size_t)blockIdx.x * blockDim.x + threadIdx.x) >> 6;
     stamps[2 * w] = t1 - t0;
@@ -100,7 +109,7 @@ template <int OP>
 void run(int wps) {
   const int threads = wps >= 8 ? 1024 : 256 * wps, grid = wps >= 8 ? 512 : 256;
   const size_t ldsb = wps >= 8 ? 70 * 1024 : 100 * 1024;
-  const int iters = 4096, per_iter = 32 * ((OP == OP_ADD64 || OP == OP_CMP_CND) ? 2 : 1);
+  const int iters = 4096, per_iter = 32 * ((OP == OP_ADD64 || OP == OP_CMP_CND || OP == OP_SALU_VALU) ? 2 : 1);
   uint32_t *o;
   unsigned long long *st;
   const size_t nw = (size_t)grid * threads / 64;
@@ -148,6 +157,6 @@ int main() {
   sweep<OP_LSHR64>(); sweep<OP_ADD64>(); sweep<OP_CMP>(); sweep<OP_PERM>(); sweep<OP_DPP>(); sweep<OP_MOV>(); sweep<OP_MAD64_32>();
   sweep<OP_CND_S>(); sweep<OP_CMP_CND>(); sweep<OP_AND>(); sweep<OP_OR>(); sweep<OP_SUB>(); sweep<OP_MIN>(); sweep<OP_LSHR_V>(); sweep<OP_BFI>();
   sweep<OP_ADD_S>(); sweep<OP_ADD_LIT>(); sweep<OP_BITOP3>(); sweep<OP_ADD3>(); sweep<OP_LSHL_OR>(); sweep<OP_SDWA>(); sweep<OP_MAD24_S>(); sweep<OP_CMP64>();
-  sweep<OP_READLANE>();
+  sweep<OP_READLANE>(); sweep<OP_SALU>(); sweep<OP_SALU64>(); sweep<OP_SALU_VALU>();
   return 0;
 }

@@ -332,6 +332,32 @@ def test_overflow_paths_are_exact(k, tuning):
     assert st["num_unique"] == wst["unique"] and st["num_purged"] == wst["purged"] and st["sum_counts"] == wst["sum_counts"]
 
 
+@pytest.mark.parametrize("k", [21, 51])
+def test_chain_positions_across_chunks_and_launches(k):
+    """The arithmetic behind the one GPU fault on record (round 2, gpurun_out/r2_b2.err: an uncommitted build of the
+    split kernels added a run's `index minus staging position`, which is kept modulo 2^32, to the staging position in
+    64 bits -- 16 GiB past the arena whenever a run starts at a smaller chain position than its place in the staging,
+    i.e. in every first round).  Chains that continue a partly filled last chunk from an earlier
+    launch and run on into new chunks, at both levels, with 16-record chunks so that every chain crosses many of them,
+    several launches with different run lengths; compact and wide records."""
+    rng = np.random.default_rng(400 + k)
+    reads, quals = random_reads(rng, 3000, min_len=k + 2, max_len=k + 120, genome_len=4000)
+    b, q, offs = arrays(reads, quals)
+    want, wtable, wst = oracle_run(b, q, offs, k)
+    cuts = [0, 7, 300, 301, 1500, 2999, 3000]  # launches of 7, 293, 1, 1199, 1499 and 1 reads
+    for tuning in (dict(writers=2, p1=4, p2=4, slots=4096, chunk1=16, chunk2=16), dict(writers=3, p1=8, p2=16, slots=2048, chunk1=16, chunk2=32)):
+        with pkg.KmerCounter(k, tuning=tuning) as kc:
+            for a, z in zip(cuts[:-1], cuts[1:]):
+                bb, qq, oo = arrays(reads[a:z], quals[a:z])
+                kc.submit_reads(bb, qq, oo)
+            gtable = kc.dump_table()
+            got = kc.sorted_results()
+            st = kc.stats()
+        assert_same(got, want)
+        assert (gtable[0] == wtable[0]).all() and (gtable[1] == wtable[1]).all() and (gtable[2] == wtable[2]).all()
+        assert st["num_unique"] == wst["unique"] and st["sum_counts"] == wst["sum_counts"]
+
+
 def test_result_arrays_grow_when_the_estimate_was_too_small():
     # max_elems far below the truth: the first vote/purge pass finds the result arrays too small (its blocks of
     # output positions run past them) and is run again with room for what it counted

@@ -179,7 +179,7 @@ def test_shard_flow_errors():
     torch.cuda.synchronize()
     with pytest.raises(pkg.KcError) as e:
         c.shard_commit(dst, w)
-    assert e.value.status == -1 and "add up" in str(e.value)
+    assert e.value.status == -1 and b"add up" in pkg.lib().kc_last_error()
     a.close()
     c.close()
 

@@ -120,6 +120,11 @@ struct kc_ctx {
   // instead of allocating again: [i] pairs with the i-th pointer of BucketBufs (bk_slots)
   struct { void *p; size_t bytes; } bk_pool[11];
   size_t bk_held[11];    // bytes behind the pointers bb holds now
+  // what the host knows without asking the device (a question is a device-to-host copy and a wait for the stream: the
+  // host pipe asked twice per block, and its copies stood still meanwhile)
+  uint64_t expect_host;  // == the device's CTR_EXPECT whenever expect_host_ok
+  bool expect_host_ok;
+  uint64_t ovf1_ub;      // upper bound of the records in the level-1 overflow list: positions launched since it was last read
   uint64_t *d_cb, *h_cb;
   bool bk_spilled;       // earlier buffer-fulls of this pass were counted and merged into the global table (bk_spill_pass)
   uint64_t expect_base;  // CTR_EXPECT when the buffer was last emptied: what is buffered now is CTR_EXPECT - expect_base
@@ -538,6 +543,9 @@ extern "C" int kc_reset(kc_ctx *c, int new_k) {
   c->bk_level2 = c->bk_flagged = c->table_mode = c->started = false;
   c->bk_spilled = false;
   c->expect_base = c->expect_prev = 0;
+  c->expect_host = 0;
+  c->expect_host_ok = true;
+  c->ovf1_ub = 0;
   shard_reset(c, c->nl != old_nl || (c->nl == 1 && new_k != old_k));
   HIPCHK(hipStreamSynchronize(c->stream));
   return KC_OK;
@@ -845,6 +853,12 @@ static void launch_ovf1_drain(kc_ctx *c, uint64_t n) {
 // many records: when the list has less room than that and holds something, its records are moved to the global table
 // first (syncs the stream).  The caller bounds its launch by the returned room.
 static int bk_ovf1_room(kc_ctx *c, uint64_t want, uint64_t *room) {
+  // no launch since the list was last read can have filled it: no need to ask (lost records, if any, are noticed when
+  // the regions are built)
+  if (c->ovf1_ub + want <= c->bb.ovf1_cap) {
+    *room = c->bb.ovf1_cap - c->ovf1_ub;
+    return KC_OK;
+  }
   int rc = sync_cb(c);
   if (rc) return rc;
   if (c->h_cb[CB_FATAL]) {
@@ -870,6 +884,7 @@ static int bk_ovf1_room(kc_ctx *c, uint64_t want, uint64_t *room) {
     HIPCHK(hipMemsetAsync(c->d_cb + CB_OVF1, 0, 8, c->stream));
     used = 0;
   }
+  c->ovf1_ub = used;
   *room = c->bb.ovf1_cap - used;
   return KC_OK;
 }
@@ -1092,8 +1107,10 @@ static void launch_extract(kc_ctx *c, const ExtractArgs &a, unsigned ntiles, int
 // One block of device-resident input through extraction, in chunks of tiles.  mode MODE_INSERT feeds this
 // shard's own k-mers to the bucketed path (or the global table once the context is in table mode);
 // MODE_BIN bins by owner shard into the caller's buffer.
+// host_occ: the block's k-mer occurrences with two neighbours where the caller has counted them on the host (the host
+// pipe: no question to the device per block then); NULL = ask the device
 static int run_extract_device(kc_ctx *c, const uint8_t *bases, const uint8_t *quals, const uint64_t *d_offsets, uint64_t nreads,
-                              uint64_t total, int mode, int fmt, uint64_t *d_records, uint64_t seg_capacity) {
+                              uint64_t total, int mode, int fmt, uint64_t *d_records, uint64_t seg_capacity, const uint64_t *host_occ = nullptr) {
   if (total == 0) return KC_OK;
   ExtractArgs a;
   memset(&a, 0, sizeof(a));
@@ -1120,11 +1137,20 @@ static int run_extract_device(kc_ctx *c, const uint8_t *bases, const uint8_t *qu
     if (bk_active(c)) {
       int rc = bk_init(c);
       if (rc) return rc;
-      rc = sync_ctrs(c);
-      if (rc) return rc;
-      if (c->h_ctrs[CTR_BAD_BASE]) return KC_ERR_BAD_BASE;
-      // the stats kernel of this block has run: CTR_EXPECT counts every occurrence submitted so far, this block included
-      const uint64_t total = c->h_ctrs[CTR_EXPECT];
+      uint64_t total;
+      if (host_occ && c->expect_host_ok) {
+        // (a bad character in an earlier block is reported by kc_flush / kc_finalize instead of by this call)
+        c->expect_host += *host_occ;
+        total = c->expect_host;
+      } else {
+        rc = sync_ctrs(c);
+        if (rc) return rc;
+        if (c->h_ctrs[CTR_BAD_BASE]) return KC_ERR_BAD_BASE;
+        // the stats kernel of this block has run: CTR_EXPECT counts every occurrence submitted so far, this block included
+        total = c->h_ctrs[CTR_EXPECT];
+        c->expect_host = total;
+        c->expect_host_ok = true;
+      }
       over_capacity = total - c->expect_base > c->bk_capacity;
       // The buffer cannot take this block on top of what it holds: count what it holds now, merge the counted k-mers
       // into the global table and go on with an empty buffer on the fast path (the reference streams insert blocks of
@@ -1137,6 +1163,8 @@ static int run_extract_device(kc_ctx *c, const uint8_t *bases, const uint8_t *qu
         over_capacity = false;
       }
       c->expect_prev = total;
+    } else {
+      c->expect_host_ok = false;  // the device goes on counting, the host does not follow
     }
   }
   int64_t p0 = 0;  // tiles of every launch start here; the bucketed kernels and the table kernel differ in tile span
@@ -1168,6 +1196,7 @@ static int run_extract_device(kc_ctx *c, const uint8_t *bases, const uint8_t *qu
       int rc = bk_ovf1_room(c, nt * span, &room);
       if (rc) return rc;
       nt = std::max<uint64_t>(1, std::min<uint64_t>(nt, room / span));
+      c->ovf1_ub += nt * span;  // what this launch can add to the list at most
       if (room < span) {  // a list smaller than one super-tile (test geometries only): nothing is bounded by it
         snprintf(g_last_error, sizeof(g_last_error), "overflow list smaller than one tile of %llu positions: raise ovf_capacity", (unsigned long long)span);
         return KC_ERR_CAPACITY;
@@ -1317,6 +1346,31 @@ static void parallel_copy(uint8_t *dst, const uint8_t *src, size_t n) {
   for (auto &t : th) t.join();
 }
 
+// k-mer occurrences with two neighbours of nr reads (what kc_read_stats_kernel adds to CTR_EXPECT), on a few threads
+static uint64_t host_occurrences(const uint64_t *offsets, uint64_t nr, int k) {
+  const unsigned hw = std::thread::hardware_concurrency();
+  const size_t nt = std::max<size_t>(1, std::min<size_t>({(size_t)8, (size_t)(hw ? hw / 2 : 2), (size_t)(nr >> 16)}));
+  std::vector<uint64_t> part(nt, 0);
+  auto work = [&](size_t t) {
+    uint64_t acc = 0;
+    for (uint64_t r = nr * t / nt, e = nr * (t + 1) / nt; r < e; r++) {
+      const uint64_t len = offsets[r + 1] - offsets[r];
+      acc += len > (uint64_t)k + 1 ? len - (uint64_t)k - 1 : 0;
+    }
+    part[t] = acc;
+  };
+  if (nt == 1) {
+    work(0);
+  } else {
+    std::vector<std::thread> th;
+    for (size_t t = 0; t < nt; t++) th.emplace_back(work, t);
+    for (auto &x : th) x.join();
+  }
+  uint64_t s = 0;
+  for (uint64_t v : part) s += v;
+  return s;
+}
+
 // a block's offsets, copied as the caller holds them, made relative to the block's first byte
 __global__ void kc_rebase_offsets_kernel(uint64_t *offs, uint64_t n, uint64_t base) {
   const uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
@@ -1417,7 +1471,9 @@ static int submit_host_reads(kc_ctx *c, const uint8_t *bases, const uint8_t *qua
     HIPCHK(hipStreamWaitEvent(c->stream, h.copied[s], 0));
     rc = raw_kmer_stats(c, h.d_offs[s], nr, mode);
     if (rc) return rc;
-    rc = run_extract_device(c, h.d_bases[s] + h.lead_b[s], h.d_quals[s] + h.lead_q[s], h.d_offs[s], nr, nb, mode, fmt, d_records, seg_capacity);
+    const uint64_t occ = host_occurrences(offsets + cur.r0, nr, c->k);
+    rc = run_extract_device(c, h.d_bases[s] + h.lead_b[s], h.d_quals[s] + h.lead_q[s], h.d_offs[s], nr, nb, mode, fmt, d_records, seg_capacity,
+                            mode == MODE_INSERT ? &occ : nullptr);
     if (rc) return rc;
     HIPCHK(hipEventRecord(h.consumed[s], c->stream));
     c->num_reads += nr;
@@ -1747,6 +1803,7 @@ extern "C" int kc_insert_records(kc_ctx *c, const uint64_t *d_records, uint64_t 
       fits = true;
     }
     c->expect_prev = c->h_ctrs[CTR_EXPECT] + n;
+    c->expect_host_ok = false;  // the records kernel adds its own count on the device
     if (!fits) {
       rc = bk_drain_to_table(c);
       if (rc) return rc;
@@ -1762,6 +1819,7 @@ extern "C" int kc_insert_records(kc_ctx *c, const uint64_t *d_records, uint64_t 
           snprintf(g_last_error, sizeof(g_last_error), "overflow list has no room: raise ovf_capacity");
           return KC_ERR_CAPACITY;
         }
+        c->ovf1_ub += m;
         const uint64_t *p = d_records + done * c->nl;
         switch (c->nl) {
           case 1: rc = launch_l1_records_t<1>(c, p, m); break;

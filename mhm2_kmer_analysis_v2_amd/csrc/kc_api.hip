@@ -1608,7 +1608,7 @@ extern "C" int kc_submit_seq_block(kc_ctx *c, const char *seqs, uint64_t len, in
     HIPCHK(hipMemcpyAsync(c->d_stage_bases, seqs, len, hipMemcpyHostToDevice, c->stream));
     d = c->d_stage_bases;
   }
-  unsigned nblk = (unsigned)std::min<uint64_t>((len + 255) / 256, 4096);
+  unsigned nblk = (unsigned)std::min<uint64_t>(((len + SEQSTAT_SPAN - 1) / SEQSTAT_SPAN + 3) / 4, 4096);  // four waves each
   hipLaunchKernelGGL(kc_seqblock_stats_kernel, dim3(nblk), dim3(256), 0, c->stream, d, len, c->k, c->d_ctrs, 1u);
   c->num_gpu_calls++;
   int rc = run_extract_device(c, d, nullptr, nullptr, 0, len, MODE_INSERT, FMT_SEQBLOCK, nullptr, 0);
@@ -1650,17 +1650,13 @@ extern "C" int kc_build_supermers(kc_ctx *c, const char *seqs, uint64_t len, int
     HIPCHK(hipMemcpyAsync(c->d_sm_bytes, seqs, len, hipMemcpyHostToDevice, c->stream));
     d = c->d_sm_bytes;
   }
-  const unsigned nblk = (unsigned)((len + 255) / 256);
   uint64_t *d_bad = (uint64_t *)(c->d_sm_ctr + 4);
-  switch (c->nl) {
-    case 1: hipLaunchKernelGGL(kc_supermer_targets_kernel<1>, dim3(nblk), dim3(256), 0, c->stream, d, len, c->k, (uint32_t)c->cfg.rank_n, c->d_sm_targets, d_bad); break;
-    case 2: hipLaunchKernelGGL(kc_supermer_targets_kernel<2>, dim3(nblk), dim3(256), 0, c->stream, d, len, c->k, (uint32_t)c->cfg.rank_n, c->d_sm_targets, d_bad); break;
-    case 3: hipLaunchKernelGGL(kc_supermer_targets_kernel<3>, dim3(nblk), dim3(256), 0, c->stream, d, len, c->k, (uint32_t)c->cfg.rank_n, c->d_sm_targets, d_bad); break;
-    default: hipLaunchKernelGGL(kc_supermer_targets_kernel<4>, dim3(nblk), dim3(256), 0, c->stream, d, len, c->k, (uint32_t)c->cfg.rank_n, c->d_sm_targets, d_bad); break;
-  }
-  hipLaunchKernelGGL(kc_supermer_build_kernel, dim3(nblk), dim3(256), 0, c->stream, c->d_sm_targets, len, c->k, c->d_sm_out, capacity,
+  if (c->k > SM_HALO - 1) return KC_ERR_UNSUPPORTED_K;
+  hipLaunchKernelGGL(kc_supermer_targets_kernel, dim3((unsigned)((len + SM_TILE - 1) / SM_TILE)), dim3(SM_WG), 0, c->stream, d, len, c->k,
+                     (uint32_t)c->cfg.rank_n, c->d_sm_targets, d_bad);
+  hipLaunchKernelGGL(kc_supermer_build_kernel, dim3((unsigned)((len + SB_WG * SB_PER - 1) / (SB_WG * SB_PER))), dim3(SB_WG), 0, c->stream, c->d_sm_targets, len, c->k, c->d_sm_out, capacity,
                      c->d_sm_ctr, c->d_sm_ctr + 1, c->d_sm_ctr + 2);
-  hipLaunchKernelGGL(kc_pack_seqs_kernel, dim3((unsigned)(((len + 1) / 2 + 255) / 256)), dim3(256), 0, c->stream, d, len, c->d_sm_packed);
+  hipLaunchKernelGGL(kc_pack_seqs_kernel, dim3((unsigned)(((len + 15) / 16 + 255) / 256)), dim3(256), 0, c->stream, d, len, c->d_sm_packed);
   c->num_gpu_calls += 3;
   HIPCHK(hipGetLastError());
   uint32_t h[6];
@@ -1700,7 +1696,7 @@ extern "C" int kc_submit_packed_supermers(kc_ctx *c, const uint8_t *packed, uint
     d = c->d_sm_packed;
   }
   uint64_t *d_bad = (uint64_t *)(c->d_sm_ctr + 4);
-  hipLaunchKernelGGL(kc_unpack_supermers_kernel, dim3((unsigned)((len + 255) / 256)), dim3(256), 0, c->stream, d, len, c->d_sm_bytes, d_bad);
+  hipLaunchKernelGGL(kc_unpack_supermers_kernel, dim3((unsigned)(((len + 7) / 8 + 255) / 256)), dim3(256), 0, c->stream, d, len, c->d_sm_bytes, d_bad);
   c->num_gpu_calls++;
   HIPCHK(hipGetLastError());
   uint32_t h[2];

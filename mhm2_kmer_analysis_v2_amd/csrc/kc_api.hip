@@ -777,11 +777,13 @@ static int bk_init(kc_ctx *c) {
   g.A2 = (uint32_t)a2;
   BucketBufs &b = c->bb;
   memset(&b, 0, sizeof(b));
-  // Overflow lists: a quarter (one-word records) or an eighth of the buffer each.  Neither can lose a record: every
-  // level-1 launch is bounded by the free room of the first (bk_ovf1_room), and level 2 is run again with a larger
-  // second list when that one was too small (bk_build_regions).
+  // Overflow lists.  Neither can lose a record: every level-1 launch is bounded by the free room of the first
+  // (bk_ovf1_room) -- a quarter (one-word records) or an eighth of the buffer, so that a block of reads goes through in
+  // a few launches -- and level 2 is run again with a second list of the size it asked for when that one was too small
+  // (bk_build_regions): the second starts at an eighth of the first (1.7 GB instead of 13 at 50 M reads).
   // (at least one super-tile of positions, whatever the buffer: a level-1 launch covers whole tiles)
-  b.ovf1_cap = b.ovf2_cap = t.ovf_capacity ? t.ovf_capacity : std::max<uint64_t>(bcap / (c->nl == 1 ? 4 : 8) + 4096, 2 * (uint64_t)SUPER_SPAN);
+  b.ovf1_cap = t.ovf_capacity ? t.ovf_capacity : std::max<uint64_t>(bcap / (c->nl == 1 ? 4 : 8) + 4096, 2 * (uint64_t)SUPER_SPAN);
+  b.ovf2_cap = t.ovf_capacity ? t.ovf_capacity : std::max<uint64_t>(bcap / (c->nl == 1 ? 32 : 64) + 4096, 2 * (uint64_t)SUPER_SPAN);
   const size_t w = (size_t)c->nl * 8;
   const size_t nseg = (size_t)g.G * g.P1;
   const size_t rec1_bytes = (size_t)g.G * g.A1 * CH1 * w, rec2_bytes = (size_t)g.A2 * CH2 * (g.cp ? 4 : w);

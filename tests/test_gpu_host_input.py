@@ -81,3 +81,32 @@ def test_blocks_of_one_long_read(small_blocks):
         got = kc.sorted_results()
     for g, w in zip(got, want):
         assert g.shape == w.shape and (g == w).all()
+
+
+def test_host_blocks_through_a_small_buffer_and_mixed_sources(small_blocks):
+    """The host pipe counts a block's occurrences itself instead of asking the device (no wait per block): the count must
+    stay right across spill passes (a buffer a quarter of the input) and when device-resident blocks, whose count only the
+    device knows, come in between."""
+    import torch
+    k = 21
+    b, q, offs, want, wst = _input(k, seed=9)
+    n = len(offs) - 1
+    cut1, cut2 = n // 3, 2 * n // 3
+
+    def part(lo, hi):
+        o = offs[lo:hi + 1] - offs[lo]
+        return b[offs[lo]:offs[hi]], q[offs[lo]:offs[hi]], o.astype(np.uint64)
+
+    occ = int(np.maximum(np.diff(offs.astype(np.int64)) - k - 1, 0).sum())
+    with pkg.KmerCounter(k, max_kmers_buffered=occ // 4) as kc:
+        kc.submit_reads(*part(0, cut1))                      # host: counted on the host
+        pb, pq, po = part(cut1, cut2)                        # device-resident: counted on the device
+        dev = torch.device("cuda", 0)
+        db, dq, do = torch.from_numpy(pb.copy()).to(dev), torch.from_numpy(pq.copy()).to(dev), torch.from_numpy(po.astype(np.int64)).to(dev)
+        kc.submit_reads(db, dq, do)                          # (the tensors stay alive until the results are out)
+        kc.submit_reads(*part(cut2, n))                      # host again: picks the device's count up first
+        got = kc.sorted_results()
+        st = kc.stats()
+    for g, w in zip(got, want):
+        assert g.shape == w.shape and (g == w).all()
+    assert st["raw_kmers"] == wst["raw_kmers"]

@@ -333,6 +333,23 @@ def test_overflow_paths_are_exact(k, tuning):
 
 
 @pytest.mark.parametrize("k", [21, 51])
+def test_second_overflow_list_grows_when_level_2_asks(k):
+    """The list of region overflows starts small (an eighth of the first list by default) and level 2 is run again with
+    the size its counter asked for: regions of at most 160 chained records, 8 of them, 60-100 k occurrences, a list of
+    20000 records (more than one tile of positions, so that level 1 may launch)."""
+    reads, quals = _reads_for_overflow(77 + k)
+    b, q, offs = arrays(reads, quals)
+    want, _, wst = oracle_run(b, q, offs, k)
+    assert wst["kmers_inserted"] > 40000  # far more than the list and the chains hold
+    with pkg.KmerCounter(k, tuning=dict(writers=2, p1=2, p2=4, slots=4096, chunk2=16, chain2_max=10, ovf_capacity=20000)) as kc:
+        kc.submit_reads(b, q, offs)
+        got = kc.sorted_results()
+        st = kc.stats()
+    assert_same(got, want)
+    assert st["num_unique"] == wst["unique"] and st["sum_counts"] == wst["sum_counts"]
+
+
+@pytest.mark.parametrize("k", [21, 51])
 def test_chain_positions_across_chunks_and_launches(k):
     """The arithmetic behind the one GPU fault on record (round 2, gpurun_out/r2_b2.err: an uncommitted build of the
     split kernels added a run's `index minus staging position`, which is kept modulo 2^32, to the staging position in

@@ -1175,11 +1175,12 @@ struct CountLDS {  // header at the start of the dynamic LDS; the arrays follow,
   uint32_t chain[2][CHAIN_LDS];
   uint32_t hdr[2][2];  // ... and its length and flag
   uint32_t nout;       // survivors of the region so far (their ranks)
+  uint32_t ncand;      // slots of the region whose k-mer was seen twice or more (the list behind the table)
   uint32_t fail[2];    // the region does not fit the table (alternating with the chain buffers)
   uint32_t gbase_lo, gbase_hi, gbase2_lo, gbase2_hi, split;  // ranks < split sit at gbase + rank, the others at gbase2 + (rank - split)
   static constexpr size_t header_bytes() { return (sizeof(CountLDS<NL>) + 15) & ~size_t(15); }
   // cp: compact records, 32-bit keys
-  static constexpr size_t bytes(uint32_t S, bool cp) { return header_bytes() + (size_t)S * ((cp ? 4 : 8 * NL) + 4 * EW) + 16; }
+  static constexpr size_t bytes(uint32_t S, bool cp) { return header_bytes() + (size_t)S * ((cp ? 4 : 8 * NL) + 4 * EW + 2) + 16; }
 };
 
 // the arrays of one region table: word w of slot s at keys[w*S + s] (the LAST word is the claim word; compact
@@ -1189,6 +1190,7 @@ struct CountLDS {  // header at the start of the dynamic LDS; the arrays follow,
 struct CountTab {
   uint64_t *keys;
   uint32_t *ext;
+  uint16_t *cand;  // S entries: the slots the vote has to look at
   uint32_t S, lgS;
 };
 
@@ -1199,6 +1201,8 @@ __device__ __forceinline__ CountTab count_tab(uint8_t *smem, uint32_t S) {
   t.keys = reinterpret_cast<uint64_t *>(p);
   p += (size_t)S * (CP ? 4 : 8 * NL);
   t.ext = reinterpret_cast<uint32_t *>(p);
+  p += (size_t)S * 4 * CountLDS<NL>::EW;
+  t.cand = reinterpret_cast<uint16_t *>(p);
   t.S = S;
   t.lgS = 31u - (uint32_t)__clz(S);
   return t;
@@ -1280,14 +1284,49 @@ __device__ __forceinline__ uint32_t lds_probe1(unsigned long long *claim, uint32
 // The probe sequence steps by an odd stride taken from the key's bits above the start slot (every slot is visited once
 // in S steps, and keys that collide on a slot part ways at once): the lanes of a wave probe in lock step, a wave pays
 // for its longest probe, and without the clusters of a unit stride the longest of 64 is shorter.
-__device__ __forceinline__ uint32_t lds_probe32(uint32_t *claim, uint32_t Sm1, uint32_t key, uint32_t slot, uint32_t stride, uint32_t valid,
+__device__ __forceinline__ uint32_t lds_probe32(uint32_t *claim, uint32_t Sm1, uint32_t key, uint32_t slot, uint32_t stride, bool valid,
                                                 uint32_t &failed) {
-  // slot and step as byte offsets (the LDS address is then the slot itself plus an immediate); a live lane's step,
-  // 0 for a lane that is done.  The kernel is bound by its vector instruction count: the two compares of a trip
-  // leave their results in scalar registers and are combined there.
+  // slot and step as byte offsets.  The loop is written out: every instruction of a trip is paid by the whole wave, the
+  // count kernel is bound by instruction issue (203 instructions per 64 records at 2.75 cycles each, §5), and what the
+  // compiler makes of the same loop in C++ is 28 instructions per trip (the lanes that are done kept out of the LDS by
+  // saving and restoring the execution mask around the compare-and-swap, the "anybody left?" test through a vector
+  // register and back).  Here the execution mask itself is the set of lanes still probing: it only shrinks, a lane's
+  // offset stops moving the moment the lane drops out, and a trip is 13 instructions.
+#ifndef KC_PROBE_CXX
+  uint32_t at = slot << 2, old, addr, trips = Sm1 + 2;
+  const uint32_t m4 = Sm1 << 2, step = stride << 2;
+  const uint32_t base = (uint32_t)(uintptr_t)claim;  // the array's LDS address (low half of the flat one)
+  const uint64_t live = __builtin_amdgcn_ballot_w64(valid);  // the lanes that hold a record (a compare's result: already a lane mask)
+  uint64_t sv, t;
+  asm volatile(
+      "s_mov_b64 %[sv], exec\n\t"
+      "s_and_b64 exec, exec, %[live]\n\t"
+      "s_cbranch_execz 2f\n"
+      "1:\n\t"
+      "v_add_u32_e32 %[addr], %[base], %[at]\n\t"
+      "ds_cmpst_rtn_b32 %[old], %[addr], %[empty], %[key]\n\t"
+      "s_waitcnt lgkmcnt(0)\n\t"
+      "v_cmp_ne_u32_e32 vcc, %[old], %[key]\n\t"    // not this key
+      "v_cmp_ne_u32_e64 %[t], -1, %[old]\n\t"       // and not (until now) empty
+      "s_and_b64 vcc, vcc, %[t]\n\t"
+      "s_and_b64 exec, exec, vcc\n\t"               // the lanes that go on
+      "s_cbranch_execz 2f\n\t"
+      "v_add_u32_e32 %[at], %[step], %[at]\n\t"
+      "v_and_b32_e32 %[at], %[m4], %[at]\n\t"
+      "s_sub_u32 %[trips], %[trips], 1\n\t"
+      "s_cmp_lg_u32 %[trips], 0\n\t"
+      "s_cbranch_scc1 1b\n\t"
+      "v_mov_b32_e32 %[fl], 1\n"                    // every slot holds some other k-mer
+      "2:\n\t"
+      "s_mov_b64 exec, %[sv]\n\t"
+      : [old] "=&v"(old), [addr] "=&v"(addr), [at] "+v"(at), [fl] "+v"(failed), [trips] "+s"(trips), [sv] "=&s"(sv), [t] "=&s"(t)
+      : [live] "s"(live), [base] "s"(base), [empty] "v"(0xFFFFFFFFu), [key] "v"(key), [step] "v"(step), [m4] "s"(m4)
+      : "vcc", "scc", "memory");
+  return at >> 2;
+#else
   uint32_t trips = 0, at = slot << 2;
   const uint32_t m4 = Sm1 << 2, step = stride << 2;
-  bool go = valid != 0;  // this lane is still probing (a lane mask in scalar registers)
+  bool go = valid;  // this lane is still probing (a lane mask in scalar registers)
   do {
     uint32_t old = key;  // a lane that is done looks like a hit below
     if (go) old = atomicCAS(reinterpret_cast<uint32_t *>(reinterpret_cast<char *>(claim) + at), 0xFFFFFFFFu, key);
@@ -1299,6 +1338,7 @@ __device__ __forceinline__ uint32_t lds_probe32(uint32_t *claim, uint32_t Sm1, u
     }
   } while (__builtin_amdgcn_ballot_w64(go) != 0);
   return at >> 2;
+#endif
 }
 
 // Several-word keys, same style: the last word is the claim word (EMPTY -> BUSY -> the key's last word), the others
@@ -1342,8 +1382,8 @@ __device__ __forceinline__ uint32_t lds_probeN(const CountTab &tb, const uint64_
 // CP: compact 32-bit records (cp_pack32); the table keys are their upper 26 bits, the k-mer is rebuilt from the
 // region and the key when an entry is written out.
 //
-// A region costs the workgroup two barriers: [inserts] barrier [one pass over the table: vote, purge, rank, write out,
-// clean the slot] barrier.  Everything a region needs from memory before its first record -- its length, its flag, its
+// A region costs the workgroup three barriers: [inserts] barrier [one pass over the table: purge the k-mers seen once,
+// list the others] barrier [the list: vote, rank, write out, clean the slot] barrier.  Everything a region needs from memory before its first record -- its length, its flag, its
 // chunk ids -- is fetched one region ahead (registers, then the other half of T.chain), and one word of every 128-byte
 // line of the next region's records is touched before the table pass, so that the record loads after the barrier
 // find their lines in the L2 instead of waiting for HBM with nothing else to do.  (Round 2 listed the occupied slots,
@@ -1389,6 +1429,7 @@ __global__ __launch_bounds__(WGB, 8) void kc_count_kernel(Geom gm, BucketBufs bb
   for (uint32_t s = tid; s < S; s += WGB) reset_slot(s);
   if (tid == 0) {
     T.nout = 0;
+    T.ncand = 0;
     T.fail[0] = T.fail[1] = 0;
   }
   // thread 0: the output blocks this workgroup holds -- the one it is filling and a spare
@@ -1442,6 +1483,7 @@ __global__ __launch_bounds__(WGB, 8) void kc_count_kernel(Geom gm, BucketBufs bb
     if (process) {
       if (tid == 0) {
         settle();
+        T.ncand = 0;  // (the last region's list was read out before the barrier that ended it)
         // room for as many survivors as this region can have: count >= 2 each, and no more than slots
         const uint64_t most = DUMP ? min(n, S) : min(n >> 1, S);
         if (out.block != 0) {
@@ -1476,6 +1518,8 @@ __global__ __launch_bounds__(WGB, 8) void kc_count_kernel(Geom gm, BucketBufs bb
         // all of them before the first wait instead of fencing each one off in its own basic block
         size_t at[BATCH];
 #pragma unroll
+        // (taking a wave's chunk id into a scalar register -- its 64 records lie in one chunk -- and adding the lanes'
+        // offsets to a scalar address saves five vector instructions per record and cost 4 ms: profiles/r03_ab_count_*)
         for (int j = 0; j < BATCH; j++) {
           uint32_t i = i0 + (uint32_t)j * WGB + tid;
           i = i < n ? i : 0u;
@@ -1494,9 +1538,9 @@ __global__ __launch_bounds__(WGB, 8) void kc_count_kernel(Geom gm, BucketBufs bb
           uint32_t failed = 0;
 #pragma unroll
           for (int j = 0; j < BATCH; j++) {
-            const uint32_t v = (i0 + (uint32_t)j * WGB + tid) < n ? 1u : 0u;
+            const bool v = (i0 + (uint32_t)j * WGB + tid) < n;
             const uint32_t r0 = rec32[j], key = r0 >> 6;
-            if (!__any(v) || KC_ABL(gm, 2)) continue;  // past the end of the region for the whole wave
+            if (__builtin_amdgcn_ballot_w64(v) == 0 || KC_ABL(gm, 2)) continue;  // past the end of the region for the whole wave
             const uint32_t s = lds_probe32(keys32, S - 1u, key, key & (S - 1u), ((key >> tb.lgS) << 1) | 1u, v, failed);
             const uint32_t le = r0 & 7u, re = (r0 >> 3) & 7u;
             // only lanes that hold a record touch the counters: the idle lanes of a wave all re-read record 0, and 64
@@ -1556,23 +1600,50 @@ __global__ __launch_bounds__(WGB, 8) void kc_count_kernel(Geom gm, BucketBufs bb
       const bool failed = T.fail[buf] != 0;  // more distinct k-mers than slots: the whole region goes to the global table instead
       const uint64_t gbase = ((uint64_t)T.gbase_hi << 32) | T.gbase_lo, gbase2 = ((uint64_t)T.gbase2_hi << 32) | T.gbase2_lo;
       const uint32_t split = T.split;
-      // S7 vote + S8 purge over the table, slot by slot; the survivors of a wave take their ranks from ONE add to the
-      // region's counter and are written straight to their places; every visited slot is left clean
+      // First the table, slot by slot: a k-mer seen once is purged on the spot (S8) -- five slots of six on reads with
+      // half a percent of errors -- and the slots seen twice or more are listed.  Then S7's vote over the LIST: a wave
+      // pays for the vote as soon as one of its lanes needs it, and with every sixth slot needing it that was every wave
+      // of the table (the vote and the write were 6 of the kernel's 23 ms); the list keeps the vote to the first few
+      // waves.  The survivors of a wave take their ranks from ONE add to the region's counter and are written straight
+      // to their places; every visited slot is left clean.
       for (uint32_t s0 = 0; s0 < S; s0 += WGB) {
         const uint32_t s = s0 + tid;
         bool taken = false;
         if (s < S) taken = CP ? keys32[s] != 0xFFFFFFFFu : tb.keys[(NL - 1) * SM + s] != KEY_EMPTY;
+        bool cand = false;
+        if (taken && !failed && !KC_ABL(gm, 3)) {
+          const uint32_t w0 = tb.ext[s], w1 = tb.ext[SM + s], w2 = tb.ext[(EW == 6 ? 2 : 4) * SM + s];
+          // the k-mer's count: every occurrence bumped exactly one of the left side's five counters (<= 65535: n is)
+          const uint32_t count = (w0 & 0xFFFFu) + (w0 >> 16) + (w1 & 0xFFFFu) + (w1 >> 16) + (w2 & 0xFFFFu);
+          cand = DUMP || count >= 2;
+          acc_entries++;
+        }
+        const uint64_t m = __ballot(cand);
+        if (m) {  // wave-uniform
+          const int leader = __ffsll((long long)m) - 1;
+          uint32_t base = 0;
+          if ((int)lane_id() == leader) base = atomicAdd(&T.ncand, (uint32_t)__popcll(m));
+          base = __shfl(base, leader);
+          if (cand) tb.cand[base + (uint32_t)__popcll(m & ((1ULL << lane_id()) - 1ULL))] = (uint16_t)s;
+        }
+        if (taken && !cand) reset_slot(s);  // leave the table clean for the next region
+      }
+      __syncthreads();
+      const uint32_t ncand = T.ncand;
+      for (uint32_t i0 = 0; i0 < ncand; i0 += WGB) {
+        const uint32_t i = i0 + tid;
+        const bool live = i < ncand;
+        const uint32_t s = live ? tb.cand[i] : 0u;
         bool keep = false;
         uint32_t count = 0, l = 0, rr = 0;
         uint32_t w[EW];
-        if (taken && !failed && !KC_ABL(gm, 3)) {
+        if (live) {
 #pragma unroll
           for (int x = 0; x < EW; x++) w[x] = tb.ext[x * SM + s];
-          // the k-mer's count: every occurrence bumped exactly one of the left side's five counters (<= 65535: n is)
           count = (w[0] & 0xFFFFu) + (w[0] >> 16) + (w[1] & 0xFFFFu) + (w[1] >> 16) + (w[EW == 6 ? 2 : 4] & 0xFFFFu);
           if (DUMP) {
             keep = true;
-          } else if (count >= 2) {
+          } else {
             const uint32_t lc[4] = {w[0] & 0xFFFFu, w[0] >> 16, w[1] & 0xFFFFu, w[1] >> 16};
             constexpr int R0 = EW == 6 ? 3 : 2;
             const uint32_t rc[4] = {w[R0] & 0xFFFFu, w[R0] >> 16, w[R0 + 1] & 0xFFFFu, w[R0 + 1] >> 16};
@@ -1580,7 +1651,6 @@ __global__ __launch_bounds__(WGB, 8) void kc_count_kernel(Geom gm, BucketBufs bb
             rr = vote_ext(rc, count, dmin_thres);
             keep = l < 4u && rr < 4u;
           }
-          acc_entries++;
         }
         const uint64_t m = __ballot(keep);
         if (m) {  // wave-uniform
@@ -1624,7 +1694,7 @@ __global__ __launch_bounds__(WGB, 8) void kc_count_kernel(Geom gm, BucketBufs bb
             acc_sum += count;
           }
         }
-        if (taken) reset_slot(s);  // leave the table clean for the next region
+        if (live) reset_slot(s);
       }
       if (failed && tid == 0) {
         bb.flag[r] = 2;
@@ -1647,7 +1717,9 @@ __global__ __launch_bounds__(WGB, 8) void kc_count_kernel(Geom gm, BucketBufs bb
     }
   }
   if (!DUMP) {
-    unsigned long long e = acc_entries, p = acc_entries - acc_kept, sm = acc_sum;
+    // (a lane's entries and its survivors are counted in different passes over different slots: the difference is only
+    // meaningful summed over the lanes, modulo 2^64)
+    unsigned long long e = acc_entries, p = (unsigned long long)acc_entries - (unsigned long long)acc_kept, sm = acc_sum;
     for (int o = 32; o > 0; o >>= 1) {
       e += __shfl_down(e, o);
       p += __shfl_down(p, o);
@@ -1655,7 +1727,7 @@ __global__ __launch_bounds__(WGB, 8) void kc_count_kernel(Geom gm, BucketBufs bb
     }
     if (lane_id() == 0) {
       if (e) atomicAdd((unsigned long long *)&cb[CB_ENTRIES], e);
-      if (p) atomicAdd((unsigned long long *)&ctrs[CTR_PURGED], p);
+      if (p) atomicAdd((unsigned long long *)&ctrs[CTR_PURGED], p);  // (may be "negative": the sum over the waves is not)
       if (sm) atomicAdd((unsigned long long *)&ctrs[CTR_SUM_COUNTS], sm);
     }
   }

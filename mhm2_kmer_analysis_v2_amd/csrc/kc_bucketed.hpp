@@ -1155,7 +1155,10 @@ __global__ __launch_bounds__(TPB) void kc_ovf1_drain_kernel(Geom gm, BucketBufs 
 }
 
 // ---- count: the LDS probe window ---------------------------------------------------------------------
-constexpr uint32_t CHAIN_LDS = 512;  // longest region chain (L2MAX) the count kernel can stage
+// longest region chain (L2MAX) the count kernel can stage.  (480, not 512: with 2048 slots of two-word keys -- 38 bytes a
+// slot with the candidate list -- two workgroups still share a CU's 160 KiB, 81744 bytes each; at 512 they missed it by
+// 150 bytes and k=33..63 counted in 38 ms instead of 28.)
+constexpr uint32_t CHAIN_LDS = 480;
 
 // LDS image of one region, structure-of-arrays so that neighbouring slots sit in neighbouring banks.
 // The table size is a power of two (cheap wrap, low load: a lane's probe sequence is as long as the run of occupied
@@ -1182,6 +1185,7 @@ struct CountLDS {  // header at the start of the dynamic LDS; the arrays follow,
   // cp: compact records, 32-bit keys
   static constexpr size_t bytes(uint32_t S, bool cp) { return header_bytes() + (size_t)S * ((cp ? 4 : 8 * NL) + 4 * EW + 2) + 16; }
 };
+static_assert(2 * CountLDS<2>::bytes(2048, false) <= 160 * 1024, "two workgroups of the two-word count kernel per CU");
 
 // the arrays of one region table: word w of slot s at keys[w*S + s] (the LAST word is the claim word; compact
 // records: one 32-bit key per slot);

@@ -82,3 +82,65 @@ def test_bad_nibble_is_reported():
         with pytest.raises(pkg.KcError) as e:
             kc.submit_packed_supermers(np.frombuffer(bytes([0x5A, 0x5B, 0x55]), dtype=np.uint8))  # 0xA, 0xB: no such codes
         assert e.value.status == -7
+
+
+@pytest.mark.parametrize("k", [21, 63])
+def test_wire_kernels_on_odd_addresses_and_lengths(k):
+    """The tile / sixteen-bytes-at-a-time kernels have an aligned fast path and a byte path: a device-resident block that
+    starts at every offset 0..16 of an allocation, lengths that are no multiple of anything (also shorter than k, one
+    character, and longer than one tile of 3840 positions), packed bytes unpacked from an odd address -- each against
+    the oracle's supermers and against the host-resident call."""
+    import ctypes as C
+    import torch
+    rng = np.random.default_rng(900 + k)
+    reads, quals = random_reads(rng, 90, min_len=k - 3, max_len=k + 140, genome_len=2500, n_rate=0.01)
+    masked = ["".join(c.lower() if ord(x) < 33 + 20 else c for c, x in zip(r, q)) for r, q in zip(reads, quals)]
+    whole = ("_".join(masked) + "_").encode()
+    o = O.Oracle(k, nranks=7, nthreads=1)
+    dev = torch.device("cuda", 0)
+    with pkg.KmerCounter(k, rank_me=0, rank_n=7) as kc:
+        for off, ln in [(0, len(whole)), (1, len(whole) - 1), (3, 5000), (7, 4097), (8, 3841), (13, 777), (16, k + 1), (5, k + 2), (2, 1), (9, 16)]:
+            block = whole[off:off + ln]
+            # what the oracle makes of the same characters: read by read (a cut may split a read: its pieces are reads)
+            want = set()
+            at = 0
+            for piece in block.decode().split("_"):
+                for t, st, l2 in o.supermers(piece):
+                    want.add((t, at + st, l2))
+                at += len(piece) + 1
+            host = kc.build_supermers(block)
+            buf = torch.zeros(len(whole) + 64, dtype=torch.uint8, device=dev)
+            buf[off:off + ln] = torch.frombuffer(bytearray(block), dtype=torch.uint8).to(dev)
+            torch.cuda.synchronize()  # (the library works on a stream of its own)
+            cap = max(16, ln)
+            out = np.zeros(cap, dtype=np.dtype([("target", np.int32), ("offset", np.int32), ("len", np.uint16), ("pad", np.uint16)]))
+            packed = np.zeros((ln + 1) // 2, dtype=np.uint8)
+            n, nk = C.c_uint32(0), C.c_uint32(0)
+            rc = pkg.lib().kc_build_supermers(kc._h, buf.data_ptr() + off, ln, 1, out.ctypes.data, cap, C.byref(n), C.byref(nk), packed.ctypes.data)
+            assert rc == 0
+            got = set(zip(out["target"][:n.value].tolist(), out["offset"][:n.value].tolist(), out["len"][:n.value].tolist()))
+            assert got == want == set(zip(host[0].tolist(), host[1].tolist(), host[2].tolist())), (off, ln)
+            assert nk.value == host[3] == sum(l2 - k - 1 for _, _, l2 in want)
+            assert (packed == host[4]).all()
+            assert unpack(packed.tobytes())[:ln] == block.decode().replace("n", "N")
+    o.close()
+    # receiver: the same packed bytes from an even and from an odd device address give the same table
+    packed_all = None
+    with pkg.KmerCounter(k, rank_me=0, rank_n=7) as kc:
+        packed_all = kc.build_supermers(whole)[4]
+    res = []
+    for shift in (0, 1, 5):
+        with pkg.KmerCounter(k) as kc:
+            d = torch.zeros(len(packed_all) + 16, dtype=torch.uint8, device=dev)
+            d[shift:shift + len(packed_all)] = torch.from_numpy(packed_all).to(dev)
+            torch.cuda.synchronize()
+            kc.submit_packed_supermers(d[shift:shift + len(packed_all)])
+            res.append(kc.sorted_results())
+    b, q, offs = O.reads_to_arrays(reads, quals)
+    o = O.Oracle(k, nranks=2, nthreads=2)
+    o.add_reads(b, q, offs)
+    want = o.finalize()
+    o.close()
+    for r in res:
+        for g, w in zip(r, want):
+            assert g.shape == w.shape and (g == w).all()

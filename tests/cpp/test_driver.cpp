@@ -21,7 +21,24 @@ int main(int argc, char **argv) {
   const int k = argc > 1 ? atoi(argv[1]) : 21;
   const std::string mode = argc > 2 ? argv[2] : "records";
   std::string block, line;
-  while (std::getline(std::cin, line)) block += line + "_";  // one case-masked read per line
+  std::vector<std::pair<int, std::string>> ctgs;  // mode "ctg": lines ">depth sequence" are contigs
+  while (std::getline(std::cin, line)) {  // one case-masked read per line
+    if (!line.empty() && line[0] == '>') {
+      const size_t sp = line.find(' ');
+      ctgs.emplace_back(atoi(line.c_str() + 1), line.substr(sp + 1));
+    } else {
+      block += line + "_";
+    }
+  }
+  auto pack = [](const std::string &read) {  // 4-bit packed as parse_and_pack.cpp:196-237 packs it
+    std::string packed((read.size() + 1) / 2, '\0');
+    for (size_t i = 0; i < read.size(); i++) {
+      const char *codes = "_acgtACGTN";
+      unsigned v = read[i] == 'n' ? 9u : (unsigned)(std::string(codes).find(read[i]));  // N and n share code 9
+      packed[i / 2] |= (char)(i % 2 ? v : v << 4);
+    }
+    return packed;
+  };
   const int R = 2;
   std::vector<std::string> out;
   std::string msgs, warnings;
@@ -72,16 +89,23 @@ int main(int argc, char **argv) {
       std::string read = block.substr(p, e - p);
       if (mode == "ascii") {
         ht[0]->insert_supermer_ascii(read);
-      } else {  // 4-bit packed as parse_and_pack.cpp:196-237 packs it
-        std::string packed((read.size() + 1) / 2, '\0');
-        for (size_t i = 0; i < read.size(); i++) {
-          const char *codes = "_acgtACGTN";
-          unsigned v = read[i] == 'n' ? 9u : (unsigned)(std::string(codes).find(read[i]));  // N and n share code 9
-          packed[i / 2] |= (char)(i % 2 ? v : v << 4);
-        }
-        ht[0]->insert_supermer(packed, 1);
+      } else {
+        ht[0]->insert_supermer(pack(read), 1);
       }
       p = e + 1;
+    }
+    if (mode == "ctg") {
+      // the second pass of a multi-round MHM2 run (kcount.cpp:106-139, kmer_dht.cpp:158-171): the table is told that
+      // contig k-mers follow, every contig arrives as a supermer whose count is the contig's depth
+      ht[0]->flush_inserts();
+      ht[0]->init_ctg_kmers(100000, 0);
+      if (ht[0]->pass_type != CTG_KMERS_PASS) return 8;
+      for (auto &c : ctgs) ht[0]->insert_supermer(pack(c.second), (count_t)c.first);
+      ht[0]->flush_inserts();
+      uint64_t attempted = 0, dropped = 0, fresh = 0;
+      ht[0]->done_ctg_kmer_inserts(attempted, dropped, fresh);
+      if (attempted != ctgs.size() || dropped) return 9;
+      std::cerr << "ctg: " << attempted << " supermers, " << fresh << " new k-mers\n";
     }
   }
   for (int r = 0; r < R; r++) {

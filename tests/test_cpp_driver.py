@@ -80,6 +80,47 @@ def test_cpp_driver_matches_oracle(tmp_path, mode):
     assert out.splitlines() == want and len(want) > 50
 
 
+@pytest.mark.gpu
+@pytest.mark.parametrize("k", [21, 31])
+def test_cpp_driver_contig_pass_matches_oracle(tmp_path, k):
+    """HashTableDriver in the contig pass, driven as kmer_dht.cpp:158-171 drives the reference's: reads, flush,
+    init_ctg_kmers, every contig as one packed supermer with its depth as the count, done_ctg_kmer_inserts,
+    done_all_inserts -- against the oracle's insert_supermer_from_ctg (kcount_cpu.cpp:357-407)."""
+    exe = build(tmp_path)
+    rng = np.random.default_rng(79 + k)
+    genome = "".join(rng.choice(list("ACGT"), size=2500))
+    reads, quals = [], []
+    for _ in range(500):
+        a = int(rng.integers(0, len(genome) - 160))
+        ln = int(rng.integers(k + 2, 150))
+        s = list(genome[a:a + ln])
+        for j in range(ln):
+            if rng.random() < 0.01:
+                s[j] = "ACGT"[int(rng.integers(0, 4))]
+        reads.append("".join(s))
+        quals.append("".join("I" if rng.random() > 0.03 else "#" for _ in range(ln)))
+    ctgs, depths = [], []
+    for i in range(30):
+        a = int(rng.integers(0, len(genome) - 400))
+        ctgs.append(genome[a:a + int(rng.integers(k + 2, 300))])
+        depths.append(int(rng.integers(1, 50)))
+    ctgs += [ctgs[0], ctgs[1][:len(ctgs[1]) // 2], "".join(rng.choice(list("ACGT"), size=300))]
+    depths += [depths[0] + 3, 2, 13]
+    masked = ["".join(c.lower() if ord(x) < 33 + 20 else c for c, x in zip(r, q)) for r, q in zip(reads, quals)]
+    text = "\n".join(masked) + "\n" + "".join(">%d %s\n" % (d, c) for c, d in zip(ctgs, depths))
+    out = subprocess.run([exe, str(k), "ctg"], input=text, capture_output=True, text=True, check=True).stdout
+    o = O.Oracle(k, nranks=1, nthreads=1)
+    b, q, offs = O.reads_to_arrays(reads, quals)
+    o.add_reads(b, q, offs)
+    for c, d in zip(ctgs, depths):
+        o.add_ctg(c, d)
+    keys, counts, left, right = o.finalize()
+    o.close()
+    want = sorted("%s %d %s %s" % (O.kmer_to_string(keys[i], k), counts[i], chr(left[i]), chr(right[i])) for i in range(len(counts)))
+    plain = O.count_reads(reads, quals, k=k)[0]
+    assert out.splitlines() == want and len(want) > len(plain[1])  # (the contigs added k-mers the reads alone do not keep)
+
+
 SURFACE = os.path.join(ROOT, "tests", "cpp", "test_surface.cpp")
 REFERENCE = "/root/reference/src"
 

@@ -91,6 +91,8 @@ class ShardExchange {
     if (s_ != KC_OK) return fail(s_, #call, kc_last_error());                          \
   } while (0)
 
+  static constexpr uint64_t POISON = ~0ULL;  // a size that says "this rank failed" in the exchange of the sizes
+
   // the previous block: what it received joins the table (compute stream, ordered behind the transfer by an event)
   int complete() {
     if (!pending.any) return KC_OK;
@@ -179,10 +181,17 @@ class ShardExchange {
       // RECORDS: the extraction is ordered behind those inserts by the compute stream itself
     }
     std::vector<uint64_t> counts((size_t)n, 0);
+    // A rank whose extraction fails (a segment too small, a bad character) must not leave the others waiting in the
+    // exchange of the sizes: it takes part with a size no block can have, and every rank returns an error together.
+    int local_rc = KC_OK;
     if (flow == BUCKETS) {
-      KCX_KC(kc_shard_extract(ctx, bases, quals, offsets, nreads, on_device, send[b], seg, counts.data()));
+      local_rc = kc_shard_extract(ctx, bases, quals, offsets, nreads, on_device, send[b], seg, counts.data());
     } else if (nreads) {
-      KCX_KC(kc_extract_partition(ctx, bases, quals, offsets, nreads, on_device, send[b], seg, counts.data()));
+      local_rc = kc_extract_partition(ctx, bases, quals, offsets, nreads, on_device, send[b], seg, counts.data());
+    }
+    if (local_rc != KC_OK) {
+      fail(local_rc, flow == BUCKETS ? "kc_shard_extract" : "kc_extract_partition", kc_last_error());
+      std::fill(counts.begin(), counts.end(), POISON);
     }
     // kc_shard_extract / kc_extract_partition return with the segments complete on the compute stream (they synchronize
     // it); the side stream is ordered behind the compute stream all the same, so that the transfers below never depend
@@ -194,6 +203,9 @@ class ShardExchange {
     KCX_NCCL(ncclAllGather(d_counts, d_all, (size_t)n, ncclUint64, comm, side));
     KCX_HIP(hipMemcpyAsync(h_all, d_all, (size_t)n * n * 8, hipMemcpyDeviceToHost, side));
     KCX_HIP(hipStreamSynchronize(side));
+    if (local_rc != KC_OK) return local_rc;
+    for (size_t i = 0; i < (size_t)n * n; i++)
+      if (h_all[i] == POISON) return fail(KC_ERR_STATE, "ShardExchange::add_block", "another rank failed to extract its block");
     const uint64_t unit = flow == BUCKETS ? 1 : (uint64_t)nl;  // words per counted thing
     uint64_t total = 0;  // BUCKETS: every sender's part starts on a 16-byte boundary
     for (int s = 0; s < n; s++)

@@ -150,9 +150,19 @@ class ShardedKmerAnalysis:
         b = self.i % 2
         self.i += 1
         # send[b] is free: its last transfer (two blocks ago) was waited for when the block after it was added
-        counts = self.extract(block, self.send[b], self.seg)
+        # A rank whose extraction fails (a segment too small, a bad character) must not leave the others waiting in the
+        # exchange of the sizes: it takes part with sizes no block can have, and every rank raises together.
+        failure = None
+        try:
+            counts = self.extract(block, self.send[b], self.seg)
+        except Exception as e:  # noqa: BLE001 -- whatever it is, it is re-raised below, after the collective
+            failure, counts = e, [-1] * self.world
         sc_host = torch.as_tensor([int(c) for c in counts], dtype=torch.int64)
         rc = exchange_counts(sc_host.to(self.device), self.group).cpu()  # the one host round trip of a block
+        if failure is not None:
+            raise failure
+        if bool((rc < 0).any()):
+            raise RuntimeError("rank(s) %s failed to extract their block" % [int(i) for i in torch.nonzero(rc < 0).flatten()])
         works, recv, n, pieces = start_exchange(self.send[b], sc_host, rc, self.seg, self.nl, self.recv[b], self.group, self.reserve)
         if self.reserve is None:
             self.recv[b] = recv

@@ -175,3 +175,40 @@ def test_two_rank_exchange_matches_single_rank_oracle(k, flow, tmp_path):
             got.append((key, cnt, l, rr))
     got.sort()
     assert got == want and len(want) > 20
+
+
+def _failing_worker(rank, world, port, tmp):
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        from mhm2_kmer_analysis_v2_amd.dist import ShardedKmerAnalysis
+
+        def extract(block, send, seg):
+            if rank == 1 and block == "bad":
+                raise ValueError("segment too small")  # what KcError(KC_ERR_CAPACITY) is to the real extract
+            return [0] * world
+
+        sk = ShardedKmerAnalysis(extract, lambda recv, n: None, 1, seg_capacity=16, device="cpu")
+        sk.add_block("fine")
+        what = "no error"
+        try:
+            sk.add_block("bad")
+        except ValueError as e:
+            what = "own: %s" % e
+        except RuntimeError as e:
+            what = "peer: %s" % e
+        with open(os.path.join(tmp, "rank%d.txt" % rank), "w") as f:
+            f.write(what)
+    finally:
+        dist.destroy_process_group()
+
+
+def test_a_failed_extraction_fails_every_rank_instead_of_hanging_the_others(tmp_path):
+    """the rank whose extract raises still takes part in the exchange of the sizes, with sizes no block can have: it
+    re-raises its own error, the others raise too (they used to wait in the collective for ever)"""
+    world = 2
+    mp.spawn(_failing_worker, args=(world, _free_port(), str(tmp_path)), nprocs=world, join=True)
+    got = [open(os.path.join(str(tmp_path), "rank%d.txt" % r)).read() for r in range(world)]
+    assert got[1] == "own: segment too small"
+    assert got[0].startswith("peer: rank(s) [1] failed")

@@ -577,7 +577,6 @@ __device__ __forceinline__ void cp_run_fixed(const TL &L, int lp0, bool active, 
     Lh ^= kc_feistel_f(Rh, 0, K);
     Rh ^= kc_feistel_f(Lh, 1, K);
     Lh ^= kc_feistel_f(Rh, 2, K);
-    Rh ^= kc_feistel_f(Lh, 3, K);
     const uint64_t mix = ((uint64_t)Lh << K) | Rh;
     lo[j] = (uint32_t)mix;
     bk[j] = valid ? ((uint32_t)(mix >> (2 * K - gm.la)) | (le << 10) | (re << 13)) : ~0u;

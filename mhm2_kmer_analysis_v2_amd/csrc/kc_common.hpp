@@ -131,8 +131,12 @@ KC_HD uint64_t kc_hash(const uint64_t (&key)[NL]) {
 // because the map is a bijection, the bits that name a record's bucket and region need not be stored with it, which
 // halves the records of the second level, and the k-mer is recovered from (region, remaining bits) when the results
 // are written.  Round function: the top k bits of the low 32 bits of x * C + D (24-bit multiply: full VALU rate).
+// Three rounds (L, R, L): bucket and region are bits of L, which a fourth round (of R) does not touch, and the slot bits
+// -- the low bits of R after one round keyed by a twice-mixed L -- spread like random ones over low-complexity families
+// too (tests/cpp/test_mix.cpp: poly-A neighbourhoods, tandem repeats, two-letter sequences, families that differ in
+// five bases at either end); the fourth round cost level 1 three vector instructions per k-mer, half a millisecond.
 KC_HD uint32_t kc_feistel_f(uint32_t x, int i, int k) {
-  const uint32_t C[4] = {0x9E3779u, 0x85EBCBu, 0xC2B2AFu, 0x27D4EBu}, D[4] = {0x7F4A7Cu, 0x165667u, 0x3C6EF3u, 0x5BD1E9u};
+  const uint32_t C[3] = {0x9E3779u, 0x85EBCBu, 0xC2B2AFu}, D[3] = {0x7F4A7Cu, 0x165667u, 0x3C6EF3u};
 #if defined(__HIP_DEVICE_COMPILE__)
   return (__umul24(x, C[i]) + D[i]) >> (32 - k);
 #else
@@ -144,12 +148,10 @@ KC_HD uint64_t kc_feistel_fwd(uint64_t v, int k) {  // v < 4^k
   L ^= kc_feistel_f(R, 0, k);
   R ^= kc_feistel_f(L, 1, k);
   L ^= kc_feistel_f(R, 2, k);
-  R ^= kc_feistel_f(L, 3, k);
   return ((uint64_t)L << k) | R;
 }
 KC_HD uint64_t kc_feistel_inv(uint64_t m, int k) {
   uint32_t L = (uint32_t)(m >> k), R = (uint32_t)m & ((1u << k) - 1u);
-  R ^= kc_feistel_f(L, 3, k);
   L ^= kc_feistel_f(R, 2, k);
   R ^= kc_feistel_f(L, 1, k);
   L ^= kc_feistel_f(R, 0, k);

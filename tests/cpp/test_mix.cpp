@@ -1,6 +1,8 @@
 // The invertible mix behind the compact records (kc_feistel_fwd / kc_feistel_inv, kc_common.hpp) on the host:
 // a permutation of the 4^k k-mers for every k it is used with, its inverse undoes it, and the bits the bucketed path
 // reads as bucket, region and probe start are spread evenly.
+#include <algorithm>
+#include <cmath>
 #include <cstdint>
 #include <cstdio>
 #include <vector>
@@ -44,6 +46,71 @@ int main() {
       if (hist[b] > 1.3 * n / P || hist2[b] > 1.3 * n / P) bad++;
     for (int s = 0; s < 2048; s++)
       if (slots[s] > 1.3 * n / 2048) bad++;
+  }
+  // low-complexity families (what real reads are full of): no bucket, region or slot more than 6.5 sigma over the mean
+  // (the fullest of 1024-2048 bins of a random assignment sits 3-4 sigma over it)
+  {
+    const int k = 21;
+    const uint64_t mask = (1ULL << (2 * k)) - 1;
+    auto canon = [&](uint64_t v) {
+      uint64_t r = 0, x = v;
+      for (int i = 0; i < k; i++) { r = (r << 2) | (3 - (x & 3)); x >>= 2; }
+      return r < v ? r : v;
+    };
+    auto check = [&](std::vector<uint64_t> &set) {
+      std::sort(set.begin(), set.end());
+      set.erase(std::unique(set.begin(), set.end()), set.end());
+      std::vector<uint32_t> b1(1024, 0), b2(1024, 0), sl(2048, 0);
+      for (uint64_t v : set) {
+        const uint64_t m = kc_feistel_fwd(v, k);
+        b1[m >> (2 * k - 10)]++;
+        b2[(m >> (2 * k - 20)) & 1023]++;
+        sl[m & 2047]++;
+      }
+      auto worst = [&](const std::vector<uint32_t> &h) {
+        const double mean = (double)set.size() / h.size();
+        uint32_t mx = 0;
+        for (uint32_t c : h) mx = c > mx ? c : mx;
+        return (mx - mean) / std::sqrt(mean);
+      };
+      return (worst(b1) > 6.5) + (worst(b2) > 6.5) + (worst(sl) > 6.5);
+    };
+    std::vector<uint64_t> s;
+    for (int a = 0; a < k; a++) for (int x = 0; x < 4; x++) for (int b = a; b < k; b++) for (int y = 0; y < 4; y++)
+      for (int c = b; c < k; c++) for (int z = 0; z < 4; z++) {  // poly-A with up to three substitutions
+        uint64_t v = (uint64_t)x << (2 * a);
+        v = (v & ~(3ULL << (2 * b))) | ((uint64_t)y << (2 * b));
+        v = (v & ~(3ULL << (2 * c))) | ((uint64_t)z << (2 * c));
+        s.push_back(canon(v & mask));
+      }
+    bad += check(s);
+    s.clear();
+    for (int p = 1; p <= 8; p++)  // tandem repeats of every unit up to 8 bases, one substitution anywhere
+      for (uint64_t unit = 0; unit < (1ULL << (2 * p)); unit++) {
+        uint64_t v = 0;
+        for (int i = 0; i < k; i++) v = (v << 2) | ((unit >> (2 * (i % p))) & 3);
+        s.push_back(canon(v));
+        if (p <= 6)
+          for (int a = 0; a < k; a++) for (int c = 1; c < 4; c++) s.push_back(canon(v ^ ((uint64_t)c << (2 * a))));
+      }
+    bad += check(s);
+    s.clear();
+    uint64_t y = 88172645463325252ULL, v = 0;
+    for (int i = 0; i < 3000000; i++) {  // a sequence over two letters
+      y ^= y << 13; y ^= y >> 7; y ^= y << 17;
+      v = ((v << 2) | ((y & 1) ? 3 : 0)) & mask;
+      if (i >= k) s.push_back(canon(v));
+    }
+    bad += check(s);
+    for (int end = 0; end < 2; end++) {  // families of 1024 that differ in five bases at one end
+      s.clear();
+      for (int g = 0; g < 2000; g++) {
+        y ^= y << 13; y ^= y >> 7; y ^= y << 17;
+        const int sh = end ? 32 : 0;
+        for (uint64_t t = 0; t < 1024; t++) s.push_back(((y & mask) & ~(1023ULL << sh)) | (t << sh));
+      }
+      bad += check(s);
+    }
   }
   std::printf("bad=%d\n", bad);
   return bad != 0;

@@ -1354,18 +1354,44 @@ __device__ __forceinline__ uint32_t lds_probeN(const CountTab &tb, const uint64_
   const unsigned long long klast = key[NL - 1];
   uint32_t act = valid, trips = 0;
   do {
-    unsigned long long old = klast;  // a lane that is done looks like a hit on its own key below
-    if (act) old = atomicCAS(&claim[slot], (unsigned long long)KEY_EMPTY, (unsigned long long)KEY_BUSY);
-    const uint32_t won = (act && old == KEY_EMPTY) ? 1u : 0u;
-    if (won) {
+    unsigned long long old;
+    uint32_t won, same;
+    if constexpr (NL >= 3) {
+      // The claim and the other words in one LDS round trip: the compare-and-swap goes out for every lane (a lane that is
+      // done expects a value no claim word ever holds, which makes it a plain read) and the reads of the other words
+      // right behind it -- the LDS serves a wave's requests in order, so a lane that finds the key published reads words
+      // that were written before the publication.  (With the reads behind the winners' writes, a trip was two trips to
+      // the LDS.)
+      old = atomicCAS(&claim[slot], act ? (unsigned long long)KEY_EMPTY : (unsigned long long)KEY_NEVER, (unsigned long long)KEY_BUSY);
+      uint64_t other[NL > 1 ? NL - 1 : 1];
 #pragma unroll
-      for (int j = 0; j < NL - 1; j++) tb.keys[j * SM + slot] = key[j];
-      __threadfence_block();  // the words are in place before the claim word says so
-      atomicExch(&claim[slot], klast);
+      for (int j = 0; j < NL - 1; j++) other[j] = tb.keys[j * SM + slot];
+      won = (act && old == KEY_EMPTY) ? 1u : 0u;
+      if (won) {
+#pragma unroll
+        for (int j = 0; j < NL - 1; j++) tb.keys[j * SM + slot] = key[j];
+        __threadfence_block();  // the words are in place before the claim word says so
+        atomicExch(&claim[slot], klast);
+      }
+      same = (old == klast || !act) ? 1u : 0u;
+#pragma unroll
+      for (int j = 0; j < NL - 1; j++) same &= (other[j] == key[j] || !act) ? 1u : 0u;
+    } else {
+      // (two-word keys: the reads every lane then issues on every trip cost more than the round trip they save: k=51
+      // count 25.4 -> 27.4 ms; three words: k=77 41.4 -> 39.7 ms, profiles/r03_ab_probe_words_with_claim.txt)
+      old = klast;  // a lane that is done looks like a hit on its own key below
+      if (act) old = atomicCAS(&claim[slot], (unsigned long long)KEY_EMPTY, (unsigned long long)KEY_BUSY);
+      won = (act && old == KEY_EMPTY) ? 1u : 0u;
+      if (won) {
+#pragma unroll
+        for (int j = 0; j < NL - 1; j++) tb.keys[j * SM + slot] = key[j];
+        __threadfence_block();  // the words are in place before the claim word says so
+        atomicExch(&claim[slot], klast);
+      }
+      same = old == klast ? 1u : 0u;
+#pragma unroll
+      for (int j = 0; j < NL - 1; j++) same &= (tb.keys[j * SM + slot] == key[j]) ? 1u : 0u;
     }
-    uint32_t same = old == klast ? 1u : 0u;
-#pragma unroll
-    for (int j = 0; j < NL - 1; j++) same &= (tb.keys[j * SM + slot] == key[j]) ? 1u : 0u;
     const uint32_t busy = old == KEY_BUSY ? 1u : 0u;
     const uint32_t hit = won | same;
     const uint32_t miss = act & ~hit & ~busy & 1u;

@@ -41,6 +41,7 @@ using TileSmall = TileGeo<TPB, TILE>;  // the global-table kernel: 4320 staged p
 
 constexpr uint64_t KEY_EMPTY = ~0ULL;
 constexpr uint64_t KEY_BUSY = ~0ULL - 1;
+constexpr uint64_t KEY_NEVER = ~0ULL - 2;  // no claim word ever holds it (a key's last word ends in six zero bits)
 
 enum { MODE_INSERT = 0, MODE_BIN = 1 };
 // input formats: ASCII bases + qualities; the reference's '_'-joined case-masked block; the reference's read

@@ -118,13 +118,14 @@ struct kc_ctx {
   BucketBufs bb;
   // arrays of an earlier geometry of this context (another k of a sweep), kept so that a later one can take them over
   // instead of allocating again: [i] pairs with the i-th pointer of BucketBufs (bk_slots)
-  struct { void *p; size_t bytes; } bk_pool[11];
-  size_t bk_held[11];    // bytes behind the pointers bb holds now
+  struct { void *p; size_t bytes; } bk_pool[13];
+  size_t bk_held[13];    // bytes behind the pointers bb holds now
   // what the host knows without asking the device (a question is a device-to-host copy and a wait for the stream: the
   // host pipe asked twice per block, and its copies stood still meanwhile)
   uint64_t expect_host;  // == the device's CTR_EXPECT whenever expect_host_ok
   bool expect_host_ok;
   uint64_t ovf1_ub;      // upper bound of the records in the level-1 overflow list: positions launched since it was last read
+  bool inc_on;           // level 2 has begun in instalments (kc_l2_split_kernel<..., INC>): bb.done1 / used2 / cnt2 carry its state
   uint64_t *d_cb, *h_cb;
   bool bk_spilled;       // earlier buffer-fulls of this pass were counted and merged into the global table (bk_spill_pass)
   uint64_t expect_base;  // CTR_EXPECT when the buffer was last emptied: what is buffered now is CTR_EXPECT - expect_base
@@ -539,6 +540,7 @@ extern "C" int kc_reset(kc_ctx *c, int new_k) {
       HIPCHK(hipMemsetAsync(c->bb.flag, 0, R * 4, c->stream));
     }
   }
+  c->inc_on = false;
   HIPCHK(hipMemsetAsync(c->d_cb, 0, CB_COUNT * 8, c->stream));
   c->bk_level2 = c->bk_flagged = c->table_mode = c->started = false;
   c->bk_spilled = false;
@@ -563,18 +565,19 @@ static uint32_t count_smax(int nl) {
 
 // the pointers of BucketBufs, in the order of kc_ctx::bk_pool
 static void bk_slots(BucketBufs &b, void ***out) {
-  void **ptrs[11] = {(void **)&b.rec1, (void **)&b.chain1, (void **)&b.cnt1, (void **)&b.used1, (void **)&b.rec2, (void **)&b.chain2,
-                     (void **)&b.cnt2, (void **)&b.base2, (void **)&b.flag, (void **)&b.ovf1, (void **)&b.ovf2};
-  for (int i = 0; i < 11; i++) out[i] = ptrs[i];
+  void **ptrs[13] = {(void **)&b.rec1, (void **)&b.chain1, (void **)&b.cnt1, (void **)&b.used1, (void **)&b.rec2, (void **)&b.chain2,
+                     (void **)&b.cnt2, (void **)&b.base2, (void **)&b.flag, (void **)&b.ovf1, (void **)&b.ovf2, (void **)&b.done1,
+                     (void **)&b.used2};
+  for (int i = 0; i < 13; i++) out[i] = ptrs[i];
 }
 
 // Give up the current geometry.  keep: its arrays stay with the context (kc_reset to another k, kc_set_tuning) and the
 // next geometry takes over every one that is large enough -- BASELINE config 5's sweep k = 21, 33, 55, 77 keeps its
 // arenas resident in HBM: they are allocated once per record width at most, and a width seen before allocates nothing.
 static void bk_free(kc_ctx *c, bool keep = false) {
-  void **slot[11];
+  void **slot[13];
   bk_slots(c->bb, slot);
-  for (int i = 0; i < 11; i++) {
+  for (int i = 0; i < 13; i++) {
     void *p = *slot[i];
     if (p && keep && c->bk_held[i] > c->bk_pool[i].bytes) {  // the larger of the two stays
       if (c->bk_pool[i].p) (void)hipFree(c->bk_pool[i].p);
@@ -800,8 +803,11 @@ static int bk_init(kc_ctx *c) {
     if (!rc) rc = bk_take(c, 8, (void **)&b.flag, (size_t)R * 4);
     if (!rc) rc = bk_take(c, 9, (void **)&b.ovf1, b.ovf1_cap * w);
     if (!rc) rc = bk_take(c, 10, (void **)&b.ovf2, b.ovf2_cap * w);
+    if (!rc) rc = bk_take(c, 11, (void **)&b.done1, nseg * 4);
+    if (!rc) rc = bk_take(c, 12, (void **)&b.used2, (size_t)g.P1 * 4);
     if (rc) return rc;
   }
+  c->inc_on = false;
   HIPCHK(hipMemsetAsync(b.cnt1, 0, nseg * 4, c->stream));
   HIPCHK(hipMemsetAsync(b.used1, 0, (size_t)g.G * 2 * 4, c->stream));
   HIPCHK(hipMemsetAsync(b.cnt2, 0, (size_t)R * 4, c->stream));
@@ -1071,12 +1077,14 @@ static int bk_drain_to_table(kc_ctx *c) {
   HIPCHK(hipMemsetAsync(c->bb.cnt1, 0, (size_t)c->gm.G * c->gm.P1 * 4, c->stream));
   HIPCHK(hipMemsetAsync(c->bb.used1, 0, (size_t)c->gm.G * 2 * 4, c->stream));
   HIPCHK(hipMemsetAsync(c->d_cb, 0, CB_COUNT * 8, c->stream));
+  c->inc_on = false;  // (what instalments of level 2 had taken is still in the level-1 chains, which went to the table whole)
   c->table_mode = true;
   return KC_OK;
 }
 
 static bool bk_active(const kc_ctx *c) { return c->tuning.mode != 1 && !c->table_mode; }
 static int bk_spill_pass(kc_ctx *c);
+static int bk_level2_instalment(kc_ctx *c);
 // A shard of several that has started the shard flow owns level-1 buckets, not hash values: the entry points that test
 // ownership per k-mer (kc_submit_*, kc_insert_records) would put records where its level 2 never looks.
 static bool shard_flow_only(const kc_ctx *c) { return c->sh.flow && c->cfg.rank_n > 1; }
@@ -1397,8 +1405,10 @@ static int submit_host_reads(kc_ctx *c, const uint8_t *bases, const uint8_t *qua
   // more per block than the copy took -- with the loop that rebased the offsets it made the pipe CPU-bound (47 GB/s over
   // a link that does 57)
   struct Blk { uint64_t r0, r1; };
+  // (the first block is an eighth of the others: nothing runs on the device until it has arrived)
+  const uint64_t total_bytes = offsets[nreads] - offsets[0];
   auto next_block = [&](uint64_t r0) {
-    const uint64_t limit = offsets[r0] + HOST_BLOCK;
+    const uint64_t limit = offsets[r0] + ((r0 == 0 && total_bytes > 4 * (uint64_t)HOST_BLOCK) ? HOST_BLOCK / 8 : HOST_BLOCK);
     uint64_t r1 = (uint64_t)(std::upper_bound(offsets + r0 + 1, offsets + nreads + 1, limit) - offsets) - 1;  // last r1 with offsets[r1] <= limit
     if (r1 <= r0) r1 = r0 + 1;
     return Blk{r0, r1};
@@ -1457,6 +1467,8 @@ static int submit_host_reads(kc_ctx *c, const uint8_t *bases, const uint8_t *qua
     h.used[s] = true;
     return KC_OK;
   };
+  const char *ie = getenv("KC_L2_INSTALMENTS");
+  const bool instalments = !(ie && ie[0] == '0');
   Blk cur = next_block(0);
   rc = stage(0, cur);
   if (rc) return rc;
@@ -1481,6 +1493,13 @@ static int submit_host_reads(kc_ctx *c, const uint8_t *bases, const uint8_t *qua
     c->num_reads += nr;
     c->num_bases += nb;
     if (!more) break;
+    // While the rest of the input is still crossing PCIe the device has time on its hands (the copies take four times
+    // as long as level 1): level 2 takes what has arrived, in instalments, so that when the last byte is in only the last
+    // block's records and the count kernel are left (end to end 186 -> 16x ms per 50 M packed reads).
+    if (mode == MODE_INSERT && instalments) {
+      rc = bk_level2_instalment(c);
+      if (rc) return rc;
+    }
     cur = nxt;
   }
   // the caller's arrays are free to change once every copy has left them
@@ -2221,14 +2240,20 @@ static int table_finalize_append(kc_ctx *c) {
 }
 
 // ---- bucketed path: regions, counting, flagged regions ------------------------------------------
+// The kernels of level 2, no host wait.  inc: an instalment (kc_l2_split_kernel<..., INC>) -- the first one fixes the
+// buckets' parts of the level-2 arena (the buffer's capacity over the fan-out each) and clears the state the
+// instalments carry; inc with c->inc_on already set: the next one.  !inc && c->inc_on never happens (bk_level2_t).
 template <int NL>
-static int bk_level2_t(kc_ctx *c) {
+static int bk_level2_launch(kc_ctx *c, bool inc) {
   // short register form: compact records whose mix fits 32 bits below the level-1 bucket
   const bool cr = use_cp<NL>(c) && c->gm.k2 - c->gm.la <= 32;
   const bool fl = shard_flow_only(c);  // only this shard's buckets, their flat sources behind their chains
-  auto kern = use_cp<NL>(c) ? (cr ? (fl ? kc_l2_split_kernel<NL, NL == 1, NL == 1, true> : kc_l2_split_kernel<NL, NL == 1, NL == 1, false>)
-                                  : (fl ? kc_l2_split_kernel<NL, NL == 1, false, true> : kc_l2_split_kernel<NL, NL == 1, false, false>))
-                            : (fl ? kc_l2_split_kernel<NL, false, false, true> : kc_l2_split_kernel<NL, false, false, false>);
+  if (inc && fl) return KC_ERR_STATE;
+  auto kern = inc ? (use_cp<NL>(c) ? (cr ? kc_l2_split_kernel<NL, NL == 1, NL == 1, false, true> : kc_l2_split_kernel<NL, NL == 1, false, false, true>)
+                                   : kc_l2_split_kernel<NL, false, false, false, true>)
+              : use_cp<NL>(c) ? (cr ? (fl ? kc_l2_split_kernel<NL, NL == 1, NL == 1, true> : kc_l2_split_kernel<NL, NL == 1, NL == 1, false>)
+                                    : (fl ? kc_l2_split_kernel<NL, NL == 1, false, true> : kc_l2_split_kernel<NL, NL == 1, false, false>))
+                              : (fl ? kc_l2_split_kernel<NL, false, false, true> : kc_l2_split_kernel<NL, false, false, false>);
   int rc = set_dyn_lds(kern, lds_l2<NL>());
   if (rc) return rc;
   FlatSrc fs;
@@ -2242,8 +2267,17 @@ static int bk_level2_t(kc_ctx *c) {
     fs.b_hi = shard_first_bucket((uint32_t)c->cfg.rank_me + 1, c->gm.P1, (uint32_t)c->cfg.rank_n);
     fs.nbo = fs.b_hi - fs.b_lo;
   }
-  hipLaunchKernelGGL(kc_bucket_prefix_kernel, dim3(1), dim3(WGB), 0, c->stream, c->gm, c->bb, fs, c->d_cb);
-  c->num_gpu_calls++;
+  if (!inc || !c->inc_on) {
+    const uint64_t per_bucket = inc ? (c->bk_capacity + c->gm.P1 - 1) / c->gm.P1 : 0;
+    hipLaunchKernelGGL(kc_bucket_prefix_kernel, dim3(1), dim3(WGB), 0, c->stream, c->gm, c->bb, fs, c->d_cb, per_bucket);
+    c->num_gpu_calls++;
+    if (inc) {
+      HIPCHK(hipMemsetAsync(c->bb.cnt2, 0, (size_t)c->gm.P1 * c->gm.P2 * 4, c->stream));
+      HIPCHK(hipMemsetAsync(c->bb.done1, 0, (size_t)c->gm.G * c->gm.P1 * 4, c->stream));
+      HIPCHK(hipMemsetAsync(c->bb.used2, 0, (size_t)c->gm.P1 * 4, c->stream));
+      c->inc_on = true;
+    }
+  }
 #ifdef KC_ABLATE
   c->gm.abl = getenv("KC_ABL_L2") ? (uint32_t)atoi(getenv("KC_ABL_L2")) : 0u;
 #endif
@@ -2252,6 +2286,25 @@ static int bk_level2_t(kc_ctx *c) {
     hipLaunchKernelGGL(kern, dim3(std::min<unsigned>(fs.b_hi - fs.b_lo, (unsigned)c->num_cus)), dim3(WGB), lds_l2<NL>(), c->stream, c->gm, c->bb,
                        fs, c->d_cb);
   }
+  HIPCHK(hipGetLastError());
+  return KC_OK;
+}
+
+// an instalment of level 2 over what has been buffered since the last one (the host pipe, between two blocks)
+static int bk_level2_instalment(kc_ctx *c) {
+  if (!bk_active(c) || !c->bk_ready || c->bk_level2 || c->sh.flow) return KC_OK;
+  switch (c->nl) {
+    case 1: return bk_level2_launch<1>(c, true);
+    case 2: return bk_level2_launch<2>(c, true);
+    case 3: return bk_level2_launch<3>(c, true);
+    default: return bk_level2_launch<4>(c, true);
+  }
+}
+
+template <int NL>
+static int bk_level2_t(kc_ctx *c) {
+  int rc = bk_level2_launch<NL>(c, c->inc_on);  // (after instalments: one more, over the rest)
+  if (rc) return rc;
   HIPCHK(hipGetLastError());
   rc = sync_cb(c);
   if (rc) return rc;
@@ -2308,6 +2361,8 @@ static int bk_build_regions(kc_ctx *c) {
     }
     // The second overflow list was too small for the regions that outgrew their chains (heavy hitters).  Level 1 is
     // untouched and the counter kept counting past the end, so it says exactly how much room the same pass needs.
+    // (After instalments the pass is run whole: the level-1 chains still hold every record.)
+    c->inc_on = false;
     const uint64_t need = c->h_cb[CB_OVF2] + c->h_cb[CB_OVF2] / 64 + 4096;
     uint64_t *bigger = nullptr;
     HIPCHK(hipMalloc((void **)&bigger, need * (size_t)c->nl * 8));
@@ -2668,6 +2723,7 @@ static int bk_spill_pass(kc_ctx *c) {
   HIPCHK(hipMemsetAsync(c->bb.flag, 0, R * 4, c->stream));
   HIPCHK(hipMemsetAsync(c->d_cb, 0, CB_COUNT * 8, c->stream));
   c->bk_level2 = c->bk_flagged = false;
+  c->inc_on = false;
   c->bk_spilled = true;
   return KC_OK;
 }

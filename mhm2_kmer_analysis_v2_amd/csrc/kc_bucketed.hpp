@@ -91,6 +91,9 @@ struct BucketBufs {
   uint64_t *ovf1;      // level-1 overflow: records without a home segment
   uint64_t *ovf2;      // level-2 overflow: records of flagged regions
   uint64_t ovf1_cap, ovf2_cap;
+  // level 2 in instalments (kc_l2_split_kernel<..., INC>): what an earlier instalment has already taken
+  uint32_t *done1;     // [G*P1] records of the chain that have been to level 2
+  uint32_t *used2;     // [P1] chunks taken from the bucket's part of the level-2 arena
 };
 
 // The shard flow (kc_shard.hpp): besides its own G chains a bucket may have flat sources -- dense runs of records
@@ -925,22 +928,26 @@ __device__ __forceinline__ const uint32_t *l2_record32(const Geom &gm, const Buc
 
 // ---- between the levels: every bucket gets a private, exactly sized part of the level-2 arena ---------
 // chunks(b) = ceil(records(b) / CH2) + P2: each of its P2 regions wastes less than one chunk
-__global__ __launch_bounds__(WGB) void kc_bucket_prefix_kernel(Geom gm, BucketBufs bb, FlatSrc fs, uint64_t *cb) {
+// per_bucket != 0 (level 2 in instalments: the parts must be fixed before the records are all there): every bucket gets
+// room for that many records -- the buffer's capacity over the fan-out; what a bucket has beyond it overflows (exact)
+__global__ __launch_bounds__(WGB) void kc_bucket_prefix_kernel(Geom gm, BucketBufs bb, FlatSrc fs, uint64_t *cb, uint64_t per_bucket) {
   __shared__ ScanLDS S;
   const uint32_t b = threadIdx.x;
   uint32_t chunks = 0;
   if (b < gm.P1) {
-    uint64_t n = 0;
-    for (uint32_t g = 0; g < gm.G; g++) n += bb.cnt1[(size_t)g * gm.P1 + b];
-    if (b >= fs.b_lo && b < fs.b_hi)
-      for (uint32_t f = 0; f < fs.F; f++) n += fs.cnt[(size_t)f * fs.nbo + (b - fs.b_lo)];
+    uint64_t n = per_bucket;
+    if (!per_bucket) {
+      for (uint32_t g = 0; g < gm.G; g++) n += bb.cnt1[(size_t)g * gm.P1 + b];
+      if (b >= fs.b_lo && b < fs.b_hi)
+        for (uint32_t f = 0; f < fs.F; f++) n += fs.cnt[(size_t)f * fs.nbo + (b - fs.b_lo)];
+    }
     chunks = (uint32_t)((n + (1u << gm.log2CH2) - 1) >> gm.log2CH2) + gm.P2;
   }
   const uint32_t e = block_excl_scan(chunks, S);
   if (b < gm.P1) bb.base2[b] = e;
   if (b == 0) {
     bb.base2[gm.P1] = S.total;
-    if (S.total > gm.A2) atomicOr((unsigned long long *)&cb[CB_FATAL], (unsigned long long)FATAL_ARENA2);  // the host keeps the buffered records within its capacity
+    if (S.total > gm.A2 && !per_bucket) atomicOr((unsigned long long *)&cb[CB_FATAL], (unsigned long long)FATAL_ARENA2);  // the host keeps the buffered records within its capacity
   }
 }
 
@@ -948,7 +955,11 @@ __global__ __launch_bounds__(WGB) void kc_bucket_prefix_kernel(Geom gm, BucketBu
 struct L2LDS {
   SplitLDS sp;
   uint32_t pre[GMAX + 1];  // prefix of the bucket's G segment lengths (+ those of its flat sources)
-  uint64_t flo[FLAT_MAX];  // shard flow: where the bucket's run starts in each flat source
+  union {                  // (never both: instalments are not for the shard flow; the four-word kernel has no LDS to spare)
+    uint64_t flo[FLAT_MAX];  // shard flow: where the bucket's run starts in each flat source
+    uint32_t skip[GMAX];     // INC: records at the head of each chain that an earlier instalment has taken
+  };
+  static_assert(sizeof(uint64_t) * FLAT_MAX >= sizeof(uint32_t) * GMAX, "skip fits in flo's place");
 };
 
 // CP: the records are mixed ones; what leaves for the regions is their 32-bit remainder (cp_pack32)
@@ -956,9 +967,15 @@ struct L2LDS {
 // split_stage between the rounds (half the registers of the full records)
 // FL: the shard flow -- only the buckets [fs.b_lo, fs.b_hi) are this shard's, and a bucket's records are its G chains
 // followed by fs.F flat sources (G + fs.F <= GMAX)
-template <int NL, bool CP, bool CR, bool FL>
+// INC: level 2 in instalments (the host pipe: the records that have arrived are split while the rest of the input is
+// still on its way over PCIe, so that only the last block's records and the count kernel are left when the last byte is
+// in).  An instalment takes, of every chain, what came after bb.done1 and goes on where the last one stopped: the
+// regions' chains (cnt2, chain2) and the bucket's share of the arena (used2) persist; the buckets' parts of the arena
+// were fixed up front (kc_bucket_prefix_kernel with per_bucket).
+template <int NL, bool CP, bool CR, bool FL, bool INC = false>
 __global__ __launch_bounds__(WGB) void kc_l2_split_kernel(Geom gm, BucketBufs bb, FlatSrc fs, uint64_t *cb) {
   static_assert(!CR || (CP && NL == 1), "the short form is one of compact records");
+  static_assert(!(INC && FL), "instalments are for a context that is not in the shard flow");
   extern __shared__ __align__(16) uint8_t smem[];
   L2LDS &L = *reinterpret_cast<L2LDS *>(smem);
   uint64_t *sorted = reinterpret_cast<uint64_t *>(smem + ((sizeof(L2LDS) + 15) & ~size_t(15)));
@@ -970,6 +987,11 @@ __global__ __launch_bounds__(WGB) void kc_l2_split_kernel(Geom gm, BucketBufs bb
     // prefix over the segments of this bucket
     {
       uint32_t v = ((uint32_t)tid < G) ? bb.cnt1[(size_t)tid * P1 + b1] : 0u;
+      if constexpr (INC) {
+        const uint32_t d = ((uint32_t)tid < G) ? bb.done1[(size_t)tid * P1 + b1] : 0u;
+        if ((uint32_t)tid < G) L.skip[tid] = d;
+        v -= d;
+      }
       if constexpr (FL) {
         if ((uint32_t)tid >= G && (uint32_t)tid < GT) {
           v = fs.cnt[(size_t)(tid - G) * fs.nbo + (b1 - fs.b_lo)];
@@ -998,7 +1020,7 @@ __global__ __launch_bounds__(WGB) void kc_l2_split_kernel(Geom gm, BucketBufs bb
     D.stamps = cb + 8;
     D.tprev = &tprev_;
 #endif
-    ChainState cst = split_load_state(L.sp, P2, nullptr, D.chain, D.LMAX, D.log2CH, 0);
+    ChainState cst = split_load_state(L.sp, P2, INC ? bb.cnt2 + (size_t)b1 * P2 : nullptr, D.chain, D.LMAX, D.log2CH, INC ? bb.used2[b1] : 0u);
     __syncthreads();
     const uint32_t n = L.pre[GT];
     const uint32_t per_round = WGB * RPOS;
@@ -1017,14 +1039,14 @@ __global__ __launch_bounds__(WGB) void kc_l2_split_kernel(Geom gm, BucketBufs bb
         const uint32_t e = min(v0 + (uint32_t)j * WGB + tid, n - 1u);
         while (e >= L.pre[p_ids + 1]) p_ids++;
         // (a record of a flat source needs no chunk id: it re-reads the table's first word, no branch)
-        const size_t ci = ((size_t)p_ids * gm.P1 + b1) * gm.L1MAX + ((e - L.pre[p_ids]) >> gm.log2CH1);
+        const size_t ci = ((size_t)p_ids * gm.P1 + b1) * gm.L1MAX + ((e - L.pre[p_ids] + (INC ? L.skip[p_ids] : 0u)) >> gm.log2CH1);
         ids[j] = bb.chain1[FL && p_ids >= G ? 0 : ci];
       }
 #pragma unroll
       for (int j = 0; j < RPOS; j++) {
         const uint32_t e = min(v0 + (uint32_t)j * WGB + tid, n - 1u);
         while (e >= L.pre[p_rec + 1]) p_rec++;
-        const uint64_t *src = bb.rec1 + (((((size_t)p_rec * gm.A1) + ids[j]) << gm.log2CH1) + ((e - L.pre[p_rec]) & CH1m)) * NL;
+        const uint64_t *src = bb.rec1 + (((((size_t)p_rec * gm.A1) + ids[j]) << gm.log2CH1) + ((e - L.pre[p_rec] + (INC ? L.skip[p_rec] : 0u)) & CH1m)) * NL;
         if constexpr (FL) {
           const uint64_t f0 = L.flo[p_rec >= G ? p_rec - G : 0u];
           if (p_rec >= G) src = reinterpret_cast<const uint64_t *>((uintptr_t)f0) + (size_t)(e - L.pre[p_rec]) * NL;
@@ -1103,6 +1125,10 @@ __global__ __launch_bounds__(WGB) void kc_l2_split_kernel(Geom gm, BucketBufs bb
       buf ^= 1;
     }
     if ((uint32_t)tid < P2) bb.cnt2[(size_t)b1 * P2 + tid] = cst.cur;
+    if constexpr (INC) {
+      if ((uint32_t)tid < G) bb.done1[(size_t)tid * P1 + b1] = L.skip[tid] + (L.pre[tid + 1] - L.pre[tid]);
+      if (tid == 0) bb.used2[b1] = min(L.sp.arena_used, D.arena_cap);
+    }
     __syncthreads();
   }
 }

@@ -869,7 +869,7 @@ static int bk_ovf1_room(kc_ctx *c, uint64_t want, uint64_t *room) {
   }
   int rc = sync_cb(c);
   if (rc) return rc;
-  if (c->h_cb[CB_FATAL]) {
+  if (c->h_cb[CB_FATAL] & ~(c->inc_on ? (uint64_t)FATAL_OVF2 : 0ULL)) {  // (an instalment's full second list is bk_build_regions' business)
     snprintf(g_last_error, sizeof(g_last_error), "k-mer buffer: records were lost (fatal bits %llu)", (unsigned long long)c->h_cb[CB_FATAL]);
     return KC_ERR_CAPACITY;
   }
@@ -1060,7 +1060,7 @@ static int bk_drain_to_table(kc_ctx *c) {
   if (rc) return rc;
   rc = sync_cb(c);
   if (rc) return rc;
-  if (c->h_cb[CB_FATAL]) {
+  if (c->h_cb[CB_FATAL] & ~(c->inc_on ? (uint64_t)FATAL_OVF2 : 0ULL)) {  // (what instalments of level 2 made is dropped here anyway)
     snprintf(g_last_error, sizeof(g_last_error), "k-mer buffer overflow lists exhausted: raise max_kmers_buffered");
     return KC_ERR_CAPACITY;
   }
@@ -1495,7 +1495,7 @@ static int submit_host_reads(kc_ctx *c, const uint8_t *bases, const uint8_t *qua
     if (!more) break;
     // While the rest of the input is still crossing PCIe the device has time on its hands (the copies take four times
     // as long as level 1): level 2 takes what has arrived, in instalments, so that when the last byte is in only the last
-    // block's records and the count kernel are left (end to end 186 -> 16x ms per 50 M packed reads).
+    // block's records and the count kernel are left (end to end 186 -> 163 ms per 50 M packed reads).
     if (mode == MODE_INSERT && instalments) {
       rc = bk_level2_instalment(c);
       if (rc) return rc;
@@ -2329,7 +2329,8 @@ static int bk_build_regions(kc_ctx *c) {
   if (c->bk_level2) return KC_OK;
   int rc = sync_cb(c);
   if (rc) return rc;
-  if (c->h_cb[CB_FATAL]) {
+  // (an instalment of level 2 may have filled the second overflow list already: the loop below deals with that)
+  if (c->h_cb[CB_FATAL] & ~(c->inc_on ? (uint64_t)FATAL_OVF2 : 0ULL)) {
     snprintf(g_last_error, sizeof(g_last_error), "k-mer buffer: records were lost at level 1 (fatal bits %llu)", (unsigned long long)c->h_cb[CB_FATAL]);
     return KC_ERR_CAPACITY;
   }

@@ -110,3 +110,27 @@ def test_host_blocks_through_a_small_buffer_and_mixed_sources(small_blocks):
     for g, w in zip(got, want):
         assert g.shape == w.shape and (g == w).all()
     assert st["raw_kmers"] == wst["raw_kmers"]
+
+
+@pytest.mark.parametrize("k,tuning", [
+    (21, None),
+    (21, dict(writers=3, p1=8, p2=16, slots=2048, chunk1=16, chunk2=16)),                                     # many chunks per chain
+    (21, dict(writers=2, p1=2, p2=4, slots=4096, chunk2=16, chain2_max=10, ovf_capacity=20000)),             # region chains overflow; the second list grows
+    (51, dict(writers=4, p1=8, p2=8, slots=128, chunk1=16, chain1_max=6, chunk2=16, chain2_max=12, ovf_capacity=1 << 20)),  # everything at once, wide records
+], ids=["default", "many-chunks", "chain2-overflow-retry", "everything-wide"])
+def test_level_2_in_instalments_equals_level_2_at_once(small_blocks, monkeypatch, k, tuning):
+    """The host pipe runs level 2 over what has arrived after every block but the last (region chains continue, every
+    bucket's part of the level-2 arena is fixed before its records are known); with KC_L2_INSTALMENTS=0 it runs once
+    at the end as before.  Both must give the oracle's set -- also where regions overflow their chains or their
+    bucket's part, and where the second overflow list has to grow (the whole pass is then run again at once)."""
+    b, q, offs, want, wst = _input(k, seed=11)
+    got = {}
+    for inst in ("1", "0"):
+        monkeypatch.setenv("KC_L2_INSTALMENTS", inst)
+        with pkg.KmerCounter(k, tuning=tuning) as kc:
+            kc.submit_reads(b, q, offs)
+            got[inst] = kc.sorted_results()
+            st = kc.stats()
+        for g, w in zip(got[inst], want):
+            assert g.shape == w.shape and (g == w).all()
+        assert st["num_unique"] == wst["unique"] and st["sum_counts"] == wst["sum_counts"]

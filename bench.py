@@ -187,8 +187,9 @@ def end_to_end(kc, k, L, d_bases, d_quals, d_offs, nreads, stage_ms):
         out[name] = {"ms_per_step": best * 1e3, "value": raw / best, "unit": "k-mers/s", "input_bytes": nbytes,
                      "input_GBps_over_pcie": nbytes / best / 1e9, "copy_only_ms": copy_s * 1e3, "copy_only_GBps": nbytes / copy_s / 1e9,
                      "overlap": {"hidden_ms": hidden_ms, "of_stage_ms": stage_ms, "frac_of_stage": hidden_ms / stage_ms}}
-    out["note"] = ("host-resident pinned input, H2D inside the timed region, results left in HBM; PCIe Gen5 x16 is 63 GB/s (spec); level 2 and "
-                   "the count kernel need every read and start after the last copy: only level 1 can hide")
+    out["note"] = ("host-resident pinned input, H2D inside the timed region, results left in HBM; PCIe Gen5 x16 is 63 GB/s (spec); level 1 "
+                   "and, in instalments, level 2 run behind the copies; the last block's share of level 2 and the count kernel come after "
+                   "the last byte")
     return out
 
 

@@ -768,7 +768,11 @@ static int bk_init(kc_ctx *c) {
   const uint64_t R = (uint64_t)g.P1 * g.P2;
   // chunk sizes: at most ~1/8 of a destination's mean share, within [16, 512] / [16, 1024] records
   const double mean1 = (double)bcap / ((double)g.G * g.P1), mean2 = flow_n * (double)bcap / (double)R;
-  g.log2CH1 = t.chunk1 ? ilog2(t.chunk1) : std::min<uint32_t>(9, std::max<uint32_t>(4, ilog2((uint64_t)(mean1 / 8) + 1)));
+  // (level-1 chunks of up to 4096 records, an eighth of a chain's mean length at most: with 512 a bucket of every wave
+  // needed a new chunk in every round, and handing those out -- an LDS counter bump the compiler serialises over the
+  // lanes, a chain entry to memory -- was a millisecond of level 1: 31.3 -> 30.0 ms, profiles/r03_tune_chunk_sizes.txt;
+  // level-2 chunks larger than 1024 make level 2 slower)
+  g.log2CH1 = t.chunk1 ? ilog2(t.chunk1) : std::min<uint32_t>(12, std::max<uint32_t>(4, ilog2((uint64_t)(mean1 / 8) + 1)));
   g.log2CH2 = t.chunk2 ? ilog2(t.chunk2) : std::min<uint32_t>(10, std::max<uint32_t>(4, ilog2((uint64_t)(mean2 / 8) + 1)));
   const uint64_t CH1 = 1ULL << g.log2CH1, CH2 = 1ULL << g.log2CH2;
   // chains may grow to several times the mean: k-mer multiplicities are heavy-tailed

@@ -1562,8 +1562,10 @@ __global__ __launch_bounds__(WGB, 8) void kc_count_kernel(Geom gm, BucketBufs bb
       }
       KC_STAMP(0)  // header
       // several independent loads in flight per thread before the dependent LDS work starts
+      // (two: with the next region's lines touched into the L2 a region ahead the loads need no depth, and eight records
+      // in registers cost spilled registers -- 19.1 -> 18.6 ms, profiles/r03_ab_count_batch.txt)
 #ifndef KC_BATCH
-#define KC_BATCH 8
+#define KC_BATCH 2
 #endif
       constexpr int BATCH = NL == 1 ? KC_BATCH : NL == 2 ? 4 : 2;
       for (uint32_t i0 = 0; i0 < n; i0 += WGB * BATCH) {

@@ -941,6 +941,19 @@ static int launch_l1_reads_t(kc_ctx *c, const ExtractArgs &a, uint64_t nsuper) {
 #ifdef KC_ABLATE
   c->gm.abl = getenv("KC_ABL_L1") ? (uint32_t)atoi(getenv("KC_ABL_L1")) : 0u;
 #endif
+  if constexpr (NL == 1) {
+    // ... and its rounds of sixteen k-mers per thread (kc_l1_reads16_kernel; KC_L1_ROUND16=0: the rounds of eight, for A/B runs)
+    static const bool round16 = !(getenv("KC_L1_ROUND16") && getenv("KC_L1_ROUND16")[0] == '0');
+    if (use_cp<NL>(c) && k21 && round16) {
+      auto kern16 = sh ? kc_l1_reads16_kernel<FMT, true, 21> : kc_l1_reads16_kernel<FMT, false, 21>;
+      int rc16 = set_dyn_lds(kern16, l1x16_lds_bytes());
+      if (rc16) return rc16;
+      KernelTimer kt(c, KT_L1_READS);
+      hipLaunchKernelGGL(kern16, dim3(grid), dim3(WGB), l1x16_lds_bytes(), c->stream, a, c->gm, c->bb, nsuper, c->bk_rot, c->d_ctrs, c->d_cb);
+      c->bk_rot = (uint32_t)((c->bk_rot + nsuper) % c->gm.G);
+      return KC_OK;
+    }
+  }
   int rc = set_dyn_lds(kern, lds_l1_reads<NL>());
   if (rc) return rc;
   KernelTimer kt(c, KT_L1_READS);

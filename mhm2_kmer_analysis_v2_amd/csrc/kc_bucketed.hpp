@@ -714,6 +714,237 @@ __global__ __launch_bounds__(WGB) void kc_l1_reads_kernel(ExtractArgs a, Geom gm
   if (lane_id() == 0 && n_ins) atomicAdd((unsigned long long *)&ctrs[CTR_INSERTED], (unsigned long long)n_ins);
 }
 
+// ---- level 1 from reads, sixteen k-mers per thread and round (compact records of a fixed k) ---------------------------
+// The rounds of kc_l1_reads_kernel stage 8192 records, eight per destination: runs of 64 bytes that touch 1.44 lines of
+// 128 bytes each, and a scan + reserve per eight k-mers of a thread.  Here a thread cuts the SIXTEEN k-mers that start in
+// its own sixteen-base group of the staged super-tile (two windows of eight, cp_run_fixed), so a super-tile is ONE round:
+// half the barriers, scans and reservations per k-mer, runs of sixteen records.  What makes 16384 staged records fit the
+// LDS beside the tile: a staged record is six bytes -- the 32 bits of the mix below the bucket in one array, bucket and
+// extension codes (16 bits) in another -- instead of the eight it has in memory; the copy-out puts the eight together
+// again.  Every destination's run starts on an EVEN position of the staging (one pad slot per destination at most), so
+// that the copy-out can take the records two at a time: a pair never straddles two destinations, one 16-byte store per
+// pair and lane (an odd run's last record, and a pair that straddles two chunks of its chain, go out as single records).
+constexpr int R16 = 16;
+constexpr uint32_t ST16_MAIN = (uint32_t)WGB * R16 + PMAX;  // a round's records + one pad per destination
+constexpr uint32_t ST16_SLOTS = ST16_MAIN + 64;             // + one slot per lane for the positions that hold no k-mer
+static_assert(SUPER_SPAN % R16 == 0 && SUPER_SPAN / R16 <= WGB, "one run of sixteen positions per thread covers the super-tile");
+static_assert(ST16_MAIN < 65536, "staging positions fit 16 bits");
+constexpr size_t l1x16_lds_bytes() { return ((sizeof(L1LDS) + 15) & ~size_t(15)) + (size_t)ST16_SLOTS * 6; }
+
+// scan (of the run lengths rounded up to even), reserve, scatter.  br[j] = bucket | extension codes << 10 | rank << 16,
+// or ~0.  dst[b] = {x, y as in split_stage, start | run length << 16, records that found room | of which in the old
+// last chunk << 16}.  Returns the staged total (pads included).
+__device__ __forceinline__ uint32_t split_stage_pairs(SplitLDS &L, uint32_t *slo, uint16_t *sbk, int buf, uint32_t P, const uint32_t (&lo)[R16],
+                                                      const uint32_t (&br)[R16], const ChainDest &D, ChainState &st) {
+  const int tid = fresh_tid();
+  const uint32_t v = ((uint32_t)tid < P) ? L.hist[buf][tid] : 0u;
+  const uint32_t excl = block_excl_scan((v + 1u) & ~1u, L.scan);
+  const uint32_t CHm = (1u << D.log2CH) - 1u;
+  if ((uint32_t)tid < P) {
+    const uint32_t base = st.cur;
+    uint32_t fit = v;
+    const uint64_t room = ((uint64_t)D.LMAX << D.log2CH) - base;  // the chain holds at most LMAX chunks
+    if ((uint64_t)fit > room) fit = (uint32_t)room;
+    const uint32_t have = (base + CHm) >> D.log2CH;
+    uint32_t k = ((base + fit + CHm) >> D.log2CH) - have, a = 0;
+    if (k) {  // (the same reservation as split_stage's)
+      const bool own = (uint32_t)tid >= D.own_lo && (uint32_t)tid < D.own_hi;
+      if (own) {
+        a = atomicAdd(&L.arena_used, k);
+        const uint32_t left = D.arena_cap - min(D.arena_cap, L.arena_top);
+        if (a + k > left) {
+          k = a < left ? left - a : 0;
+          const uint64_t cap = ((uint64_t)(have + k) << D.log2CH) - base;
+          if ((uint64_t)fit > cap) fit = (uint32_t)cap;
+        }
+      } else {
+        const uint32_t t = atomicAdd(&L.arena_top, k);
+        const uint32_t left = D.arena_cap - min(D.arena_cap, L.arena_used);
+        if (t + k > left) {
+          k = 0;
+          const uint64_t cap = ((uint64_t)have << D.log2CH) - base;
+          if ((uint64_t)fit > cap) fit = (uint32_t)cap;
+        } else {
+          a = D.arena_cap - t - k;
+        }
+      }
+      uint32_t *ch = D.chain + (size_t)tid * D.LMAX + have;
+      for (uint32_t i = 0; i < k; i++) ch[i] = D.arena_base + a + i;
+    }
+    uint4 d;
+    d.x = ((st.last - D.arena_base - (base >> D.log2CH)) << D.log2CH) + base - excl;
+    d.y = ((a - have) << D.log2CH) + base - excl;
+    d.z = excl | (v << 16);
+    d.w = fit | (((base & CHm) ? min(fit, (CHm + 1u) - (base & CHm)) : 0u) << 16);
+    L.dst[tid] = d;
+    if (k) st.last = D.arena_base + a + k - 1;
+    st.cur = base + fit;
+    L.hist[buf ^ 1][tid] = 0;  // next round's histogram
+  }
+  lds_barrier();
+  const uint32_t total = L.scan.total;
+#pragma unroll
+  for (int j0 = 0; j0 < R16; j0 += 8) {
+    uint32_t pos[8];
+#pragma unroll
+    for (int j = 0; j < 8; j++) pos[j] = L.dst[br[j0 + j] & (PMAX - 1)].z;
+#pragma unroll
+    for (int j = 0; j < 8; j++) {
+      const uint32_t bj = br[j0 + j];
+      const uint32_t p = bj != ~0u ? (pos[j] & 0xFFFFu) + (bj >> 16) : ST16_MAIN + lane_id();
+      slo[p] = lo[j0 + j];
+      sbk[p] = (uint16_t)bj;
+    }
+  }
+  lds_barrier();
+  return total;
+}
+
+// two staged records (one destination) as one 16-byte store; the address is 8-byte aligned
+struct __attribute__((aligned(8))) RecPair {
+  uint64_t a, b;
+};
+
+template <class OvfFn>
+__device__ __forceinline__ void split_copy_out_pairs(SplitLDS &L, const uint32_t *slo, const uint16_t *sbk, uint32_t total, const ChainDest &D,
+                                                     const Geom &gm, OvfFn overflow) {
+  const int tid = fresh_tid();
+  constexpr int U = 4;  // pairs per thread and trip: first all their records, then all their destinations, then the stores
+  uint64_t *const arena0 = D.arena + ((size_t)D.arena_base << D.log2CH);
+  const uint32_t shb = 32u - gm.la, shl = 64u - gm.k2;  // the bucket in the high word; the 32 bits below it start here (shl < 32)
+  for (uint32_t i0 = 2u * (uint32_t)tid; i0 < total; i0 += 2u * U * WGB) {
+    uint64_t lo2[U];
+    uint32_t bk2[U];
+    uint4 d[U];
+#pragma unroll
+    for (int u = 0; u < U; u++) {
+      const uint32_t i = i0 + 2u * (uint32_t)u * WGB;
+      const uint32_t ii = i < total ? i : i0;  // in range: i0 < total
+      lo2[u] = *reinterpret_cast<const uint64_t *>(slo + ii);
+      bk2[u] = *reinterpret_cast<const uint32_t *>(sbk + ii);
+    }
+#pragma unroll
+    for (int u = 0; u < U; u++) d[u] = L.dst[bk2[u] & (PMAX - 1)];
+    bool odd = false;
+#pragma unroll
+    for (int u = 0; u < U; u++) {
+      const uint32_t i = i0 + 2u * (uint32_t)u * WGB;
+      const uint32_t j = i - (d[u].z & 0xFFFFu), v = d[u].z >> 16, fit = d[u].w & 0xFFFFu, wold = d[u].w >> 16;
+      const bool live = i < total;  // (a pair's first position always holds a record: runs start on even positions)
+      const bool f0 = live && j < fit, real1 = live && j + 1u < v, f1 = real1 && j + 1u < fit;
+      // x and y are "index minus staging position" modulo 2^32: the sums must wrap in 32 bits before they are widened
+      const uint32_t at0 = (j < wold ? d[u].x : d[u].y) + i, at1 = (j + 1u < wold ? d[u].x : d[u].y) + i + 1u;
+      const uint32_t l0 = (uint32_t)lo2[u], l1 = (uint32_t)(lo2[u] >> 32);
+      const uint32_t bh = (bk2[u] & (PMAX - 1)) << shb;
+      RecPair r;
+      r.a = ((uint64_t)(bh | (l0 >> (32u - shl))) << 32) | (uint64_t)((l0 << shl) | ((bk2[u] >> 10) & 63u));
+      r.b = ((uint64_t)(bh | (l1 >> (32u - shl))) << 32) | (uint64_t)((l1 << shl) | (bk2[u] >> 26));
+      const bool pair = f0 && f1 && at1 == at0 + 1u;
+      if (pair) *reinterpret_cast<RecPair *>(arena0 + at0) = r;
+      else if (f0) arena0[at0] = r.a;
+      odd |= (real1 && !pair) || (live && !f0);
+    }
+    if (__any(odd)) {  // seldom: a pair across two chunks of its chain; a full chain or arena
+#pragma unroll
+      for (int u = 0; u < U; u++) {
+        const uint32_t i = i0 + 2u * (uint32_t)u * WGB;
+        if (i >= total) continue;
+        const uint32_t j = i - (d[u].z & 0xFFFFu), v = d[u].z >> 16, fit = d[u].w & 0xFFFFu, wold = d[u].w >> 16;
+        const uint32_t at0 = (j < wold ? d[u].x : d[u].y) + i, at1 = (j + 1u < wold ? d[u].x : d[u].y) + i + 1u;
+        const uint32_t l0 = (uint32_t)lo2[u], l1 = (uint32_t)(lo2[u] >> 32);
+        const uint32_t bh = (bk2[u] & (PMAX - 1)) << shb;
+        const uint64_t ra = ((uint64_t)(bh | (l0 >> (32u - shl))) << 32) | (uint64_t)((l0 << shl) | ((bk2[u] >> 10) & 63u));
+        const uint64_t rb = ((uint64_t)(bh | (l1 >> (32u - shl))) << 32) | (uint64_t)((l1 << shl) | (bk2[u] >> 26));
+        const bool f0 = j < fit, real1 = j + 1u < v, f1 = real1 && j + 1u < fit;
+        if (!f0) overflow(ra);
+        if (real1 && !(f0 && f1 && at1 == at0 + 1u)) {
+          if (f1) arena0[at1] = rb;
+          else overflow(rb);
+        }
+      }
+    }
+  }
+}
+
+template <int FMT, bool SH, int KK>
+__global__ __launch_bounds__(WGB) void kc_l1_reads16_kernel(ExtractArgs a, Geom gm, BucketBufs bb, uint64_t nsuper, uint32_t rot, uint64_t *ctrs,
+                                                            uint64_t *cb) {
+  extern __shared__ __align__(16) uint8_t smem[];
+  L1LDS &L = *reinterpret_cast<L1LDS *>(smem);
+  uint32_t *slo = reinterpret_cast<uint32_t *>(smem + ((sizeof(L1LDS) + 15) & ~size_t(15)));
+  uint16_t *sbk = reinterpret_cast<uint16_t *>(slo + ST16_SLOTS);
+  const int tid = threadIdx.x;
+  const uint32_t g = (blockIdx.x + rot) % gm.G, P1 = gm.P1;
+  const ChainDest D = l1_dest<1>(gm, bb, g);
+  ChainState cst = split_load_state(L.sp, P1, bb.cnt1 + (size_t)g * P1, D.chain, D.LMAX, D.log2CH, bb.used1[g], bb.used1[gm.G + g]);
+  __syncthreads();
+  uint32_t n_ins = 0;
+  int buf = 0;
+  TileRaw<TileSuper> raw;  // the next super-tile's bytes, on their way while this one is split (kc_l1_reads_kernel)
+  auto first_of = [&](uint64_t st) -> uint64_t { return (FMT != FMT_SEQBLOCK && st < nsuper) ? a.tile_first[st] : 0; };
+  tile_prefetch<FMT, TileSuper>(raw, a, a.pos0 + (int64_t)blockIdx.x * SUPER_SPAN, tid, first_of(blockIdx.x), blockIdx.x < nsuper);
+  uint64_t next_first = first_of((uint64_t)blockIdx.x + gridDim.x);
+  constexpr int RUNS = SUPER_SPAN / R16;
+  // iteration -1 only stages the first super-tile; every further one is staged between its predecessor's scatter and
+  // copy-out (one place in the code for the staging)
+  for (int64_t it = -1;; it++) {
+    const uint64_t st = (uint64_t)blockIdx.x + (uint64_t)(it < 0 ? 0 : it) * gridDim.x;
+    const bool work = it >= 0;  // the same for every thread of the workgroup
+    if (work && st >= nsuper) break;
+    uint32_t total = 0;
+    if (work) {
+      uint32_t lo[R16], br[R16];
+      const bool active = tid < RUNS;
+      const int lp0 = PRE + (active ? tid : 0) * R16;
+      {
+        uint32_t l8[8], b8[8];
+        cp_run_fixed<KK, 8, SH>(L.tile, lp0, active, gm, a, l8, b8);
+#pragma unroll
+        for (int j = 0; j < 8; j++) {
+          lo[j] = l8[j];
+          br[j] = b8[j];
+        }
+        cp_run_fixed<KK, 8, SH>(L.tile, lp0 + 8, active, gm, a, l8, b8);
+#pragma unroll
+        for (int j = 0; j < 8; j++) {
+          lo[8 + j] = l8[j];
+          br[8 + j] = b8[j];
+        }
+      }
+#pragma unroll
+      for (int j = 0; j < R16; j++) {
+        const bool valid = br[j] != ~0u;
+        const uint32_t rank = hist_rank(L.sp, buf, br[j] & (PMAX - 1), valid);
+        br[j] = valid ? (br[j] | (rank << 16)) : ~0u;
+        n_ins += valid ? 1u : 0u;
+      }
+      lds_barrier();
+      total = split_stage_pairs(L.sp, slo, sbk, buf, P1, lo, br, D, cst);
+    }
+    {
+      // every k-mer of this super-tile has left it (the barrier after the histogram): stage the next one now
+      const uint64_t nst = work ? st + gridDim.x : st;
+      tile_encode<FMT, TileSuper>(L.tile, raw, a, a.pos0 + (int64_t)nst * SUPER_SPAN, ctrs, tid, nst < nsuper);
+      tile_prefetch<FMT, TileSuper>(raw, a, a.pos0 + (int64_t)(nst + gridDim.x) * SUPER_SPAN, tid, next_first, nst + gridDim.x < nsuper);
+      next_first = first_of(nst + 2 * (uint64_t)gridDim.x);
+    }
+    if (work) {
+      split_copy_out_pairs(L.sp, slo, sbk, total, D, gm, [&](uint64_t r) {
+        const uint64_t rr[1] = {r};
+        l1_overflow<1, true>(gm, bb, cb, rr);
+      });
+      buf ^= 1;
+    }
+  }
+  if ((uint32_t)tid < P1) bb.cnt1[(size_t)g * P1 + tid] = cst.cur;
+  if (tid == 0) {
+    bb.used1[g] = min(L.sp.arena_used, gm.A1);
+    bb.used1[gm.G + g] = min(L.sp.arena_top, gm.A1);
+  }
+  for (int o = 32; o > 0; o >>= 1) n_ins += __shfl_down(n_ins, o);
+  if (lane_id() == 0 && n_ins) atomicAdd((unsigned long long *)&ctrs[CTR_INSERTED], (unsigned long long)n_ins);
+}
+
 // ---- sender side of the shard exchange: bin a block's records by owner shard ------------------------------
 // Same tile extraction and ranking as level 1, with the owner shard as the bucket and the caller's per-shard segments
 // as destinations: one global cursor bump per shard and round (a handful of atomics per 8 Ki records) instead of one

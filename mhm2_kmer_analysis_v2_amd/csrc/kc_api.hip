@@ -2326,9 +2326,9 @@ static int bk_level2_t(kc_ctx *c) {
   rc = sync_cb(c);
   if (rc) return rc;
 #ifdef KC_STAMPS
-  fprintf(stderr, "l2 kernel cycles (thread 0, summed over workgroups): load+hist %llu barrierA %llu scan+reserve %llu scatter %llu copyout %llu\n",
+  fprintf(stderr, "l2 kernel cycles (thread 0, summed over workgroups): hist %llu barrierA %llu scan+reserve %llu scatter %llu copyout %llu take-over+loads %llu\n",
           (unsigned long long)c->h_cb[8], (unsigned long long)c->h_cb[9], (unsigned long long)c->h_cb[10],
-          (unsigned long long)c->h_cb[11], (unsigned long long)c->h_cb[12]);
+          (unsigned long long)c->h_cb[11], (unsigned long long)c->h_cb[12], (unsigned long long)c->h_cb[13]);
   HIPCHK(hipMemsetAsync(c->d_cb + 8, 0, 8 * 8, c->stream));
 #endif
   const uint64_t n1 = std::min<uint64_t>(c->h_cb[CB_OVF1], c->bb.ovf1_cap);

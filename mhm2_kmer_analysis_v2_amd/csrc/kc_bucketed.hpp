@@ -353,6 +353,9 @@ __device__ __forceinline__ uint32_t split_stage(SplitLDS &L, uint64_t *sorted, u
     L.dst[tid] = d;
     if (k) st.last = D.arena_base + a + k - 1;
     st.cur = base + fit;
+    // the scatter takes a run's start from the histogram's word, which has served its purpose: a dense array of words
+    // spreads over all the banks, the .z of 16-byte entries over a quarter of them
+    L.hist[buf][tid] = excl;
     L.hist[buf ^ 1][tid] = 0;  // next round's histogram
   }
   lds_barrier();
@@ -366,11 +369,11 @@ __device__ __forceinline__ uint32_t split_stage(SplitLDS &L, uint64_t *sorted, u
     for (int j0 = 0; j0 < R; j0 += H) {
       uint32_t pos[H];
 #pragma unroll
-      for (int j = 0; j < H; j++) pos[j] = L.dst[br[j0 + j] & (PMAX - 1)].z;
+      for (int j = 0; j < H; j++) pos[j] = L.hist[buf][br[j0 + j] & (PMAX - 1)];
 #pragma unroll
       for (int j = 0; j < H; j++) {
         const uint32_t bj = br[j0 + j];
-        const uint32_t p = bj != ~0u ? (pos[j] & 0xFFFFu) + (bj >> RS) : (uint32_t)(R * WGB) + lane_id();
+        const uint32_t p = bj != ~0u ? pos[j] + (bj >> RS) : (uint32_t)(R * WGB) + lane_id();
         uint64_t r[NL];
         rec_of(j0 + j, r);
 #pragma unroll
@@ -557,7 +560,10 @@ __device__ __forceinline__ void cp_run_fixed(const TL &L, int lp0, bool active, 
 #pragma unroll
   for (int j = 0; j < RPOS; j++) {
     const uint64_t x = Wn >> (64 - 2 * (j + K + 2)), y = Rn >> (64 - 2 * (RPOS - 1 - j + K + 2));
-    const bool swap = (y & MID) < (x & MID);  // strict: a palindrome keeps the forward extensions
+    // strict: a palindrome keeps the forward extensions.  An odd k has no palindromes: the k-mers always differ, the right
+    // neighbours below them never decide, and only the bases above the slice need masking (one AND per side, not two)
+    constexpr uint64_t CMP = (K & 1) ? (MID | 3ULL) : MID;
+    const bool swap = (y & CMP) < (x & CMP);
     const uint64_t sel = swap ? y : x;
     // extension codes: the slice's outer bases, bit 2 set where the base may not serve as one
     const uint32_t na = (nok >> j) & 1u, nb = (nok >> (j + K + 1)) & 1u;
@@ -737,6 +743,7 @@ constexpr size_t l1x16_lds_bytes() { return ((sizeof(L1LDS) + 15) & ~size_t(15))
 __device__ __forceinline__ uint32_t split_stage_pairs(SplitLDS &L, uint32_t *slo, uint16_t *sbk, int buf, uint32_t P, const uint32_t (&lo)[R16],
                                                       const uint32_t (&br)[R16], const ChainDest &D, ChainState &st) {
   const int tid = fresh_tid();
+  KC_SPLIT_STAMP(1)  // barrier after the histogram
   const uint32_t v = ((uint32_t)tid < P) ? L.hist[buf][tid] : 0u;
   const uint32_t excl = block_excl_scan((v + 1u) & ~1u, L.scan);
   const uint32_t CHm = (1u << D.log2CH) - 1u;
@@ -779,24 +786,29 @@ __device__ __forceinline__ uint32_t split_stage_pairs(SplitLDS &L, uint32_t *slo
     L.dst[tid] = d;
     if (k) st.last = D.arena_base + a + k - 1;
     st.cur = base + fit;
+    // the scatter takes a run's start from the histogram's word, which has served its purpose: a dense array of words
+    // spreads over all the banks, the .z of 16-byte entries over a quarter of them
+    L.hist[buf][tid] = excl;
     L.hist[buf ^ 1][tid] = 0;  // next round's histogram
   }
   lds_barrier();
+  KC_SPLIT_STAMP(2)  // scan + reserve
   const uint32_t total = L.scan.total;
 #pragma unroll
   for (int j0 = 0; j0 < R16; j0 += 8) {
     uint32_t pos[8];
 #pragma unroll
-    for (int j = 0; j < 8; j++) pos[j] = L.dst[br[j0 + j] & (PMAX - 1)].z;
+    for (int j = 0; j < 8; j++) pos[j] = L.hist[buf][br[j0 + j] & (PMAX - 1)];
 #pragma unroll
     for (int j = 0; j < 8; j++) {
       const uint32_t bj = br[j0 + j];
-      const uint32_t p = bj != ~0u ? (pos[j] & 0xFFFFu) + (bj >> 16) : ST16_MAIN + lane_id();
+      const uint32_t p = bj != ~0u ? pos[j] + (bj >> 16) : ST16_MAIN + lane_id();
       slo[p] = lo[j0 + j];
       sbk[p] = (uint16_t)bj;
     }
   }
   lds_barrier();
+  KC_SPLIT_STAMP(3)  // scatter to LDS
   return total;
 }
 
@@ -864,6 +876,7 @@ __device__ __forceinline__ void split_copy_out_pairs(SplitLDS &L, const uint32_t
       }
     }
   }
+  KC_SPLIT_STAMP(4)  // copy-out
 }
 
 template <int FMT, bool SH, int KK>
@@ -875,7 +888,12 @@ __global__ __launch_bounds__(WGB) void kc_l1_reads16_kernel(ExtractArgs a, Geom 
   uint16_t *sbk = reinterpret_cast<uint16_t *>(slo + ST16_SLOTS);
   const int tid = threadIdx.x;
   const uint32_t g = (blockIdx.x + rot) % gm.G, P1 = gm.P1;
-  const ChainDest D = l1_dest<1>(gm, bb, g);
+  ChainDest D = l1_dest<1>(gm, bb, g);
+#ifdef KC_STAMPS
+  unsigned long long tprev_ = __builtin_amdgcn_s_memtime();
+  D.stamps = cb + 8;
+  D.tprev = &tprev_;
+#endif
   ChainState cst = split_load_state(L.sp, P1, bb.cnt1 + (size_t)g * P1, D.chain, D.LMAX, D.log2CH, bb.used1[g], bb.used1[gm.G + g]);
   __syncthreads();
   uint32_t n_ins = 0;
@@ -918,6 +936,7 @@ __global__ __launch_bounds__(WGB) void kc_l1_reads16_kernel(ExtractArgs a, Geom 
         br[j] = valid ? (br[j] | (rank << 16)) : ~0u;
         n_ins += valid ? 1u : 0u;
       }
+      KC_SPLIT_STAMP(0)  // cut the k-mers out of the super-tile, histogram
       lds_barrier();
       total = split_stage_pairs(L.sp, slo, sbk, buf, P1, lo, br, D, cst);
     }
@@ -927,6 +946,7 @@ __global__ __launch_bounds__(WGB) void kc_l1_reads16_kernel(ExtractArgs a, Geom 
       tile_encode<FMT, TileSuper>(L.tile, raw, a, a.pos0 + (int64_t)nst * SUPER_SPAN, ctrs, tid, nst < nsuper);
       tile_prefetch<FMT, TileSuper>(raw, a, a.pos0 + (int64_t)(nst + gridDim.x) * SUPER_SPAN, tid, next_first, nst + gridDim.x < nsuper);
       next_first = first_of(nst + 2 * (uint64_t)gridDim.x);
+      KC_SPLIT_STAMP(5)  // stage the next super-tile
     }
     if (work) {
       split_copy_out_pairs(L.sp, slo, sbk, total, D, gm, [&](uint64_t r) {
@@ -1429,7 +1449,10 @@ constexpr uint32_t CHAIN_LDS = 480;
 template <int NL>
 struct CountLDS {  // header at the start of the dynamic LDS; the arrays follow, strided by the region's S
   static constexpr uint32_t SMAX = NL <= 2 ? 4096 : 2048;
-  static constexpr int EW = NL == 1 ? 6 : 5;  // extension words per slot
+  // extension words per slot.  (Compact records have the room for eight, a side's words then picked by the raw 3-bit
+  // code with no clamping: four vector instructions less per record and 0.5 ms MORE, profiles/r04_ab_count_eight_words.txt
+  // -- more words to sum in the table pass and to clear per slot, a larger table to spread the adds over)
+  static constexpr int ew(bool) { return NL == 1 ? 6 : 5; }
   // the region's chunk ids; two buffers: the next region's ids are fetched while this one is counted
   uint32_t chain[2][CHAIN_LDS];
   uint32_t hdr[2][2];  // ... and its length and flag
@@ -1439,7 +1462,7 @@ struct CountLDS {  // header at the start of the dynamic LDS; the arrays follow,
   uint32_t gbase_lo, gbase_hi, gbase2_lo, gbase2_hi, split;  // ranks < split sit at gbase + rank, the others at gbase2 + (rank - split)
   static constexpr size_t header_bytes() { return (sizeof(CountLDS<NL>) + 15) & ~size_t(15); }
   // cp: compact records, 32-bit keys
-  static constexpr size_t bytes(uint32_t S, bool cp) { return header_bytes() + (size_t)S * ((cp ? 4 : 8 * NL) + 4 * EW + 2) + 16; }
+  static constexpr size_t bytes(uint32_t S, bool cp) { return header_bytes() + (size_t)S * ((cp ? 4 : 8 * NL) + 4 * ew(cp) + 2) + 16; }
 };
 static_assert(2 * CountLDS<2>::bytes(2048, false) <= 160 * 1024, "two workgroups of the two-word count kernel per CU");
 
@@ -1461,7 +1484,7 @@ __device__ __forceinline__ CountTab count_tab(uint8_t *smem, uint32_t S) {
   t.keys = reinterpret_cast<uint64_t *>(p);
   p += (size_t)S * (CP ? 4 : 8 * NL);
   t.ext = reinterpret_cast<uint32_t *>(p);
-  p += (size_t)S * 4 * CountLDS<NL>::EW;
+  p += (size_t)S * 4 * CountLDS<NL>::ew(CP);
   t.cand = reinterpret_cast<uint16_t *>(p);
   t.S = S;
   t.lgS = 31u - (uint32_t)__clz(S);
@@ -1683,7 +1706,7 @@ __global__ __launch_bounds__(WGB, 8) void kc_count_kernel(Geom gm, BucketBufs bb
   CountLDS<NL> &T = *reinterpret_cast<CountLDS<NL> *>(smem);
   const int tid = threadIdx.x;
   const uint32_t S = gm.S, SM = gm.S;
-  constexpr int EW = CountLDS<NL>::EW;
+  constexpr int EW = CountLDS<NL>::ew(CP);
   const CountTab tb = count_tab<NL, CP>(smem, S);
   const size_t R = (size_t)gm.P1 * gm.P2;
   // diagnostic builds only (-DKC_STAMPS): thread 0 accumulates the cycles between the phase boundaries of every region
@@ -1879,7 +1902,7 @@ __global__ __launch_bounds__(WGB, 8) void kc_count_kernel(Geom gm, BucketBufs bb
       if (has_next) {
         const uint32_t n_nxt = T.hdr[buf ^ 1][0], f_nxt = T.hdr[buf ^ 1][1];
         constexpr uint32_t PER_LINE = CP ? 32u : 16u / NL;  // records per 128 bytes
-        const uint32_t i = (uint32_t)tid * PER_LINE;
+        const uint32_t i = (uint32_t)fresh_tid() * PER_LINE;  // (recomputed: hoisted out of the region loop the address was spilled)
         if (f_nxt == 0 && n_nxt <= KC_COUNT_MAX && i < n_nxt && (i >> gm.log2CH2) < npre) {
           const size_t a = ((size_t)T.chain[buf ^ 1][i >> gm.log2CH2] << gm.log2CH2) + (i & CHm);
           touch = CP ? reinterpret_cast<const uint32_t *>(bb.rec2)[a] : (uint32_t)bb.rec2[a * NL];
@@ -1900,8 +1923,8 @@ __global__ __launch_bounds__(WGB, 8) void kc_count_kernel(Geom gm, BucketBufs bb
         if (s < S) taken = CP ? keys32[s] != 0xFFFFFFFFu : tb.keys[(NL - 1) * SM + s] != KEY_EMPTY;
         bool cand = false;
         if (taken && !failed && !KC_ABL(gm, 3)) {
-          const uint32_t w0 = tb.ext[s], w1 = tb.ext[SM + s], w2 = tb.ext[(EW == 6 ? 2 : 4) * SM + s];
-          // the k-mer's count: every occurrence bumped exactly one of the left side's five counters (<= 65535: n is)
+          const uint32_t w0 = tb.ext[s], w1 = tb.ext[SM + s], w2 = tb.ext[(EW == 5 ? 4 : 2) * SM + s];
+          // the k-mer's count: every occurrence bumped exactly one of the left side's counters (<= 65535: n is)
           const uint32_t count = (w0 & 0xFFFFu) + (w0 >> 16) + (w1 & 0xFFFFu) + (w1 >> 16) + (w2 & 0xFFFFu);
           cand = DUMP || count >= 2;
           acc_entries++;
@@ -1928,7 +1951,7 @@ __global__ __launch_bounds__(WGB, 8) void kc_count_kernel(Geom gm, BucketBufs bb
         if (live) {
 #pragma unroll
           for (int x = 0; x < EW; x++) w[x] = tb.ext[x * SM + s];
-          count = (w[0] & 0xFFFFu) + (w[0] >> 16) + (w[1] & 0xFFFFu) + (w[1] >> 16) + (w[EW == 6 ? 2 : 4] & 0xFFFFu);
+          count = (w[0] & 0xFFFFu) + (w[0] >> 16) + (w[1] & 0xFFFFu) + (w[1] >> 16) + (w[EW == 5 ? 4 : 2] & 0xFFFFu);
           if (DUMP) {
             keep = true;
           } else {

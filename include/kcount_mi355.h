@@ -282,9 +282,16 @@ int kc_begin_ctg_kmers(kc_ctx *ctx, uint64_t max_ctg_kmers);
  * kc_finalize then returns what the reference's insert_into_local_hashtable would after inserting the contigs behind
  * the reads: the reads' results, plus the contig k-mers that are not among them, whose occurrences agree on both
  * extensions (both bases) and all have a depth of 2 or more, with the smallest depth as their count (kc_ctg.hpp).
- * KC_ERR_BAD_BASE for a character outside ACGTN (the reference DIEs), KC_ERR_CAPACITY when more distinct k-mers came than
- * kc_begin_ctg_kmers made room for. */
+ * KC_ERR_BAD_BASE for a character outside ACGTN anywhere in the block (the reference DIEs), KC_ERR_CAPACITY when more
+ * distinct k-mers came than kc_begin_ctg_kmers made room for (the table is never filled beyond three quarters: a block is
+ * taken in as many launches as its free room asks for).  A context that is one of several ranks (rank_n > 1) keeps of a
+ * block only the k-mers the read path would keep there -- its share by the k-mer hash, by the reference's target rank
+ * (KC_FLAG_REFERENCE_OWNER) or, in the shard flow, by the owner of the k-mer's level-1 bucket -- so every rank may be
+ * given every contig, or (like the C++ driver, whose host routes supermers by target) only its own. */
 int kc_submit_ctg_block(kc_ctx *ctx, const char *seqs, const uint16_t *depths, uint64_t len, int on_device);
+/* The contig pass so far: distinct contig k-mers in its table (what done_ctg_kmer_inserts reports as new inserts,
+ * gpu_hash_table.cpp:697-734) and characters submitted.  Either pointer may be null. */
+int kc_ctg_stats(kc_ctx *ctx, uint64_t *distinct, uint64_t *positions);
 
 /* KmerDHT::flush_updates -> HashTableInserter::flush_inserts (kmer_dht.cpp:252-258): wait for submitted work. */
 int kc_flush(kc_ctx *ctx);
@@ -341,6 +348,11 @@ typedef struct kc_kernel_time {
   double total_ms;
 } kc_kernel_time;
 int kc_get_kernel_times(kc_ctx *ctx, kc_kernel_time *out, int max, int *n);
+/* TB/s at which the level-1 arena this context chose took level 1's write pattern for a millisecond when it was
+ * allocated (the better of two allocations is kept: which physical memory the driver hands out decides the rate, see
+ * DESIGN.md section 5); 0 when no probe ran (arenas under a GiB, KC_ARENA_PROBE=0, the global-table path).  Lets a
+ * caller see a slow draw; the library asks no absolute rate of an arena. */
+int kc_arena_probe_rate(kc_ctx *ctx, double *tbps);
 int kc_clear_kernel_times(kc_ctx *ctx);
 
 /* ---- synthetic ArcticSynth-shaped reads (bench / tests) ------- */

@@ -92,6 +92,8 @@ SYMBOLS = {
     "kc_copy_results": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]),
     "kc_begin_ctg_kmers": (C.c_int, [C.c_void_p, C.c_uint64]),
     "kc_submit_ctg_block": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_uint64, C.c_int]),
+    "kc_ctg_stats": (C.c_int, [C.c_void_p, C.POINTER(C.c_uint64), C.POINTER(C.c_uint64)]),
+    "kc_arena_probe_rate": (C.c_int, [C.c_void_p, C.POINTER(C.c_double)]),
     "kc_copy_results_entries": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p]),
     "kc_lookup": (C.c_int, [C.c_void_p, C.c_void_p, C.c_uint64, C.c_int, C.c_void_p, C.c_void_p, C.c_void_p]),
     "kc_dump_table": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.POINTER(C.c_uint64)]),

@@ -39,11 +39,12 @@ static int hip_fail(hipError_t e, const char *what, int line) {
   } while (0)
 
 enum { KT_EXTRACT_INSERT = 0, KT_EXTRACT_BIN, KT_INSERT_RECORDS, KT_FINALIZE, KT_TILE_FIRST, KT_REHASH, KT_L1_READS, KT_L1_RECORDS,
-       KT_L2_SPLIT, KT_COUNT_REGIONS, KT_FALLBACK, KT_SHARD_PACK, KT_COUNT };
+       KT_L2_SPLIT, KT_COUNT_REGIONS, KT_FALLBACK, KT_SHARD_PACK, KT_L1_READS_UQ, KT_L1_READS16, KT_COUNT };
 static const char *const kt_names[KT_COUNT] = {"kc_extract_kernel<insert>", "kc_bin_reads_kernel", "kc_insert_records_kernel",
                                                "kc_finalize_kernel", "kc_tile_first_kernel", "kc_rehash_kernel",
                                                "kc_l1_reads_kernel", "kc_l1_records_kernel", "kc_l2_split_kernel",
-                                               "kc_count_kernel", "kc_flagged_to_table_kernel", "kc_shard_pack_kernel"};
+                                               "kc_count_kernel", "kc_flagged_to_table_kernel", "kc_shard_pack_kernel",
+                                               "kc_l1_reads_kernel<byte-loaded qualities>", "kc_l1_reads16_kernel"};
 struct kt_pending {
   hipEvent_t start, stop;
   int kind;
@@ -96,6 +97,7 @@ struct kc_ctx {
   uint64_t ctg_cap;
   uint64_t *d_ctg_status;  // [0] a character outside the alphabet was seen, [1] entries
   uint64_t ctg_attempted, ctg_new;
+  double arena_probe_tbps;  // rate of level 1's write pattern on the arena pick_fast_arena chose (0: no probe ran)
   kc_synth_table *d_synth;
   // scratch of the reference-wire entry points (kc_build_supermers, kc_submit_packed_supermers)
   uint8_t *d_sm_bytes;    // block / unpacked block
@@ -636,37 +638,36 @@ static uint32_t ilog2(uint64_t v) {
 // brings most slow ones back fast), and one that is still slow is HELD while another is asked for (when the device has
 // the room), at most four in all; the fastest is kept.  First processes on a freshly started box draw slow arenas most often.
 // KC_ARENA_PROBE=0 switches this off, =1 logs.
-// A large allocation serves the split kernels' scattered appends better once it has been written from end to end, given
-// back and asked for again (the same memory returns): level 2 26.1 ms instead of 27.0 ms on average over eight processes
-// each, slow level-1 arenas mostly turn fast (measured; how the driver backs memory it hands out for the first time is
-// the suspect).  Costs a memset at set-up time.
-static int scrub_allocation(kc_ctx *c, uint64_t **p, size_t bytes) {
-  HIPCHK(hipMemsetAsync(*p, 0, bytes, c->stream));
-  HIPCHK(hipStreamSynchronize(c->stream));
-  HIPCHK(hipFree(*p));
-  *p = nullptr;
-  HIPCHK(hipMalloc((void **)p, bytes));
-  return KC_OK;
-}
-
+// The rate at which an arena takes level 1's write pattern (many interleaved append streams) depends on which physical
+// memory the driver backed it with -- uniform over the allocation, not changed by re-mapping it, out of the
+// application's reach (profiles/r03_arena_alloc_probe.txt, r03_arena_permute_pieces.txt): one millisecond of the pattern
+// tells.  The yardstick is the arena's OWN first GiB: confined to one GiB the same pattern runs at the same rate on every
+// allocation, fast or slow (4.9-5.1 TB/s over twenty allocations of ten processes, profiles/r04_arena_selection.txt),
+// while spread over the whole arena it runs at 0.97-1.1 of that on most allocations, at 0.85-0.9 on some (level 1
+// 27.3-27.7 instead of 26.5-27.1 ms) and at 0.7-0.75 on the slow ones (30 ms).  So an allocation is taken at once when
+// its whole-arena rate reaches KC_ARENA_OK of its first-GiB rate -- a ratio, no rate in TB/s is asked of anything --
+// and otherwise it is HELD while another is asked for (the same memory comes back otherwise), up to three, while the
+// device has room to hold them; the best ratio wins.  The chosen arena's rate is reported (kc_arena_probe_rate;
+// KC_ARENA_PROBE=1 logs every candidate), so that a caller can see a slow draw.
+constexpr double KC_ARENA_OK = 0.93;
 static int pick_fast_arena(kc_ctx *c, uint64_t **arena, size_t bytes, uint32_t G, const char *what) {
   const char *pe = getenv("KC_ARENA_PROBE");
   hipEvent_t e0, e1;
   HIPCHK(hipEventCreate(&e0));
   HIPCHK(hipEventCreate(&e1));
   const uint32_t rounds = 256;
-  const size_t wpw = bytes / 8 / G;
+  const size_t wpw = bytes / 8 / G, wpw_gib = std::min<size_t>(wpw, ((size_t)1 << 30) / 8 / G);
   const double probe_bytes = (double)G * rounds * 65536.0;
-  constexpr int NCAND = 4;
-  uint64_t *cand[NCAND] = {*arena, nullptr, nullptr, nullptr};
-  double rate[NCAND] = {0, 0, 0, 0};
+  constexpr int NCAND = 3;
+  uint64_t *cand[NCAND] = {*arena, nullptr, nullptr};
+  double rate[NCAND] = {0, 0, 0}, ratio[NCAND] = {0, 0, 0};
   int ncand = 1;
-  auto probe = [&](uint64_t *p) -> double {  // TB/s of the write pattern on p, the better of two runs; < 0: a HIP call failed
+  auto probe = [&](uint64_t *p, size_t words_per_wg) -> double {  // TB/s of the write pattern on p, the better of two runs; < 0: a HIP call failed
     float best = 1e30f;
     for (int rep = 0; rep < 2; rep++) {
       float ms = 0;
       if (hipEventRecord(e0, c->stream) != hipSuccess) return -1.0;
-      hipLaunchKernelGGL(kc_arena_probe_kernel, dim3(G), dim3(WGB), 0, c->stream, p, wpw, rounds);
+      hipLaunchKernelGGL(kc_arena_probe_kernel, dim3(G), dim3(WGB), 0, c->stream, p, words_per_wg, rounds);
       if (hipEventRecord(e1, c->stream) != hipSuccess || hipEventSynchronize(e1) != hipSuccess || hipEventElapsedTime(&ms, e0, e1) != hipSuccess)
         return -1.0;
       best = std::min(best, ms);
@@ -676,12 +677,12 @@ static int pick_fast_arena(kc_ctx *c, uint64_t **arena, size_t bytes, uint32_t G
   const bool log = pe || getenv("KC_DEBUG_ADDR");
   int rc = KC_OK;
   for (int i = 0; i < NCAND && !rc; i++) {
-    rc = scrub_allocation(c, &cand[i], bytes);  // (on failure cand[i] is null or still valid: the clean-up below copes)
-    if (rc) break;
-    rate[i] = probe(cand[i]);
-    if (rate[i] < 0) rc = KC_ERR_HIP;
-    if (log) fprintf(stderr, "kc arena probe (%s): allocation %d, %.2f TB/s, %p\n", what, i, rate[i], (void *)cand[i]);
-    if (rc || rate[i] >= 4.8 || i == NCAND - 1) break;
+    rate[i] = probe(cand[i], wpw);
+    const double gib = probe(cand[i], wpw_gib);
+    if (rate[i] < 0 || gib <= 0) rc = KC_ERR_HIP;
+    else ratio[i] = rate[i] / gib;
+    if (log) fprintf(stderr, "kc arena probe (%s): allocation %d, %.2f TB/s, %.2f of its first GiB alone, %p\n", what, i, rate[i], ratio[i], (void *)cand[i]);
+    if (rc || ratio[i] >= KC_ARENA_OK || i == NCAND - 1) break;
     size_t free_b = 0, total_b = 0;
     if (hipMemGetInfo(&free_b, &total_b) != hipSuccess || free_b < bytes + ((size_t)8 << 30)) break;  // no room to hold another
     if (hipMalloc((void **)&cand[i + 1], bytes) != hipSuccess) {
@@ -693,10 +694,11 @@ static int pick_fast_arena(kc_ctx *c, uint64_t **arena, size_t bytes, uint32_t G
   }
   int best_i = -1;
   for (int i = 0; i < ncand; i++)
-    if (cand[i] && (best_i < 0 || rate[i] > rate[best_i])) best_i = i;
+    if (cand[i] && (best_i < 0 || ratio[i] > ratio[best_i])) best_i = i;
   for (int i = 0; i < ncand; i++)
     if (i != best_i && cand[i]) (void)hipFree(cand[i]);
   *arena = best_i >= 0 ? cand[best_i] : nullptr;
+  c->arena_probe_tbps = best_i >= 0 ? rate[best_i] : 0.0;
   (void)hipEventDestroy(e0);
   (void)hipEventDestroy(e1);
   if (!rc && !*arena) rc = KC_ERR_OUT_OF_MEMORY;
@@ -797,6 +799,14 @@ static int bk_init(kc_ctx *c) {
   bool rec1_reused = false, rec2_reused = false;
   {
     int rc = bk_take(c, 0, (void **)&b.rec1, rec1_bytes, &rec1_reused);
+    // The level-1 arena is chosen before anything else is allocated (pick_fast_arena; for every arena of a GiB or more:
+    // below that a stage is over before the difference shows; an arena taken over from an earlier geometry has been
+    // chosen already).  (Chosen last, a second candidate that won lay behind the level-2 arena in allocation order, and
+    // level 2 then took 28 instead of 26 ms: profiles/r04_arena_selection.txt.)
+    const char *pe = getenv("KC_ARENA_PROBE");
+    if (!rc && !(pe && pe[0] == '0') && rec1_bytes >= ((size_t)1 << 30) && !rec1_reused) {
+      rc = pick_fast_arena(c, &b.rec1, rec1_bytes, g.G, "level 1");
+    }
     if (!rc) rc = bk_take(c, 1, (void **)&b.chain1, nseg * g.L1MAX * 4);
     if (!rc) rc = bk_take(c, 2, (void **)&b.cnt1, nseg * 4);
     if (!rc) rc = bk_take(c, 3, (void **)&b.used1, (size_t)g.G * 2 * 4);
@@ -817,24 +827,6 @@ static int bk_init(kc_ctx *c) {
   HIPCHK(hipMemsetAsync(b.cnt2, 0, (size_t)R * 4, c->stream));
   HIPCHK(hipMemsetAsync(b.flag, 0, (size_t)R * 4, c->stream));
   HIPCHK(hipMemsetAsync(c->d_cb, 0, CB_COUNT * 8, c->stream));
-  // The arenas are written as many interleaved append streams (level 1: G x P1, level 2: P2 per bucket workgroup), a
-  // pattern whose speed depends on how the driver happened to back the allocation: pick_fast_arena
-  {
-    const char *pe = getenv("KC_ARENA_PROBE");
-    // (for every arena of a GiB or more: below that a stage is over before the difference shows)
-    if (!(pe && pe[0] == '0') && rec1_bytes >= ((size_t)1 << 30)) {
-      // (an arena taken over from an earlier geometry has been written and chosen already)
-      if (!rec2_reused) {
-        int rc2 = scrub_allocation(c, &b.rec2, rec2_bytes);
-        if (rc2) return rc2;
-      }
-      // (level 2's arena was tried too: its probe does not predict level 2's time, which moves by only 4 %)
-      if (!rec1_reused) {
-        int rc = pick_fast_arena(c, &b.rec1, rec1_bytes, g.G, "level 1");
-        if (rc) return rc;
-      }
-    }
-  }
   if (getenv("KC_DEBUG_ADDR"))
     fprintf(stderr, "kc arenas: rec1 %p (%zu MB) chain1 %p cnt1 %p rec2 %p chain2 %p ovf1 %p ovf2 %p\n", (void *)b.rec1, rec1_bytes >> 20,
             (void *)b.chain1, (void *)b.cnt1, (void *)b.rec2, (void *)b.chain2, (void *)b.ovf1, (void *)b.ovf2);
@@ -948,7 +940,7 @@ static int launch_l1_reads_t(kc_ctx *c, const ExtractArgs &a, uint64_t nsuper) {
       auto kern16 = sh ? kc_l1_reads16_kernel<FMT, true, 21> : kc_l1_reads16_kernel<FMT, false, 21>;
       int rc16 = set_dyn_lds(kern16, l1x16_lds_bytes());
       if (rc16) return rc16;
-      KernelTimer kt(c, KT_L1_READS);
+      KernelTimer kt(c, FMT == FMT_READS_UQ ? KT_L1_READS_UQ : KT_L1_READS16);
       hipLaunchKernelGGL(kern16, dim3(grid), dim3(WGB), l1x16_lds_bytes(), c->stream, a, c->gm, c->bb, nsuper, c->bk_rot, c->d_ctrs, c->d_cb);
       c->bk_rot = (uint32_t)((c->bk_rot + nsuper) % c->gm.G);
       return KC_OK;
@@ -956,7 +948,7 @@ static int launch_l1_reads_t(kc_ctx *c, const ExtractArgs &a, uint64_t nsuper) {
   }
   int rc = set_dyn_lds(kern, lds_l1_reads<NL>());
   if (rc) return rc;
-  KernelTimer kt(c, KT_L1_READS);
+  KernelTimer kt(c, FMT == FMT_READS_UQ ? KT_L1_READS_UQ : KT_L1_READS);
   hipLaunchKernelGGL(kern, dim3(grid), dim3(WGB), lds_l1_reads<NL>(), c->stream, a, c->gm, c->bb, nsuper, c->bk_rot, c->d_ctrs, c->d_cb);
   c->bk_rot = (uint32_t)((c->bk_rot + nsuper) % c->gm.G);
   return KC_OK;
@@ -1467,8 +1459,14 @@ static int submit_host_reads(kc_ctx *c, const uint8_t *bases, const uint8_t *qua
     h.lead_b[s] = lead_of(sb, pinned ? bases : h.h_bases[s]);
     h.lead_q[s] = with_quals ? lead_of(sq, pinned ? quals : h.h_quals[s]) : 0u;
     if (with_quals) {
+      // The two leads come from two buffers of the caller's: when they differ modulo 16 the qualities land up to 15 bytes
+      // further into their slot (the source of the copy stays on its page boundary), so that a read's bases and
+      // qualities sit at device addresses equal modulo 16 and level 1 keeps its 16-byte loads (FMT_READS; otherwise
+      // every block of such an input fell back to the byte loads of FMT_READS_UQ)
+      const uint32_t shift = (h.lead_b[s] - h.lead_q[s]) & 15u;
       HIPCHK(hipMemcpyAsync(h.d_bases[s], sb - h.lead_b[s], nb + h.lead_b[s], hipMemcpyHostToDevice, h.copy_stream));
-      HIPCHK(hipMemcpyAsync(h.d_quals[s], sq - h.lead_q[s], nb + h.lead_q[s], hipMemcpyHostToDevice, h.copy_stream2));
+      HIPCHK(hipMemcpyAsync(h.d_quals[s] + shift, sq - h.lead_q[s], nb + h.lead_q[s], hipMemcpyHostToDevice, h.copy_stream2));
+      h.lead_q[s] += shift;
     } else {
       const uint64_t tot = nb + h.lead_b[s], h1 = (tot / 2) & ~(uint64_t)4095;
       const uint8_t *src = sb - h.lead_b[s];
@@ -2979,28 +2977,71 @@ extern "C" int kc_submit_ctg_block(kc_ctx *c, const char *seqs, const uint16_t *
     d_seqs = tmp;
     d_depths = td;
   }
-  const unsigned nblk = (unsigned)((len + 255) / 256);
-  switch (c->nl) {
-    case 1: hipLaunchKernelGGL(kc_ctg_insert_kernel<1>, dim3(nblk), dim3(256), 0, c->stream, d_seqs, d_depths, len, c->k, c->ctg_table, c->d_ctg_status); break;
-    case 2: hipLaunchKernelGGL(kc_ctg_insert_kernel<2>, dim3(nblk), dim3(256), 0, c->stream, d_seqs, d_depths, len, c->k, c->ctg_table, c->d_ctg_status); break;
-    case 3: hipLaunchKernelGGL(kc_ctg_insert_kernel<3>, dim3(nblk), dim3(256), 0, c->stream, d_seqs, d_depths, len, c->k, c->ctg_table, c->d_ctg_status); break;
-    default: hipLaunchKernelGGL(kc_ctg_insert_kernel<4>, dim3(nblk), dim3(256), 0, c->stream, d_seqs, d_depths, len, c->k, c->ctg_table, c->d_ctg_status); break;
+  // which k-mers this context keeps: everything as one rank; as one of several, what the read path keeps there
+  CtgOwn own;
+  memset(&own, 0, sizeof(own));
+  own.mode = CTG_OWN_ALL;
+  own.rank_me = (uint32_t)c->cfg.rank_me;
+  own.rank_n = (uint32_t)c->cfg.rank_n;
+  int rc = KC_OK;
+  if (c->cfg.rank_n > 1) {
+    if (c->sh.flow || (c->cfg.flags & KC_FLAG_SHARD_BUCKETS)) {  // the shard flow: the owner of the k-mer's level-1 bucket
+      rc = bk_active(c) ? bk_init(c) : KC_ERR_STATE;
+      own.mode = CTG_OWN_BUCKET;
+      own.gm = c->gm;
+      own.own_lo = shard_first_bucket((uint32_t)c->cfg.rank_me, c->gm.P1, (uint32_t)c->cfg.rank_n);
+      own.own_hi = shard_first_bucket((uint32_t)c->cfg.rank_me + 1, c->gm.P1, (uint32_t)c->cfg.rank_n);
+    } else {
+      own.mode = (c->cfg.flags & KC_FLAG_REFERENCE_OWNER) ? CTG_OWN_REFERENCE : CTG_OWN_HASH;
+    }
   }
-  c->num_gpu_calls++;
-  hipError_t e = hipGetLastError();
-  uint64_t st[2] = {0, 0};
-  if (e == hipSuccess) e = hipMemcpyAsync(st, c->d_ctg_status, 16, hipMemcpyDeviceToHost, c->stream);
-  if (e == hipSuccess) e = hipStreamSynchronize(c->stream);
+  // A launch may add as many distinct k-mers as it has positions: it gets no more positions than the table has room for
+  // below three quarters, so that a probe always ends at an empty slot (an estimate that is too low -- the driver passes
+  // the reference's -- must end in KC_ERR_CAPACITY, not in a kernel that never returns).
+  hipError_t e = hipSuccess;
+  uint64_t st[2] = {0, c->ctg_new};
+  for (uint64_t p0 = 0; rc == KC_OK && p0 < len;) {
+    const uint64_t limit = c->ctg_cap / 4 * 3;
+    if (st[1] >= limit) {
+      snprintf(g_last_error, sizeof(g_last_error), "contig pass: %llu distinct k-mers fill the table kc_begin_ctg_kmers made (%llu slots)",
+               (unsigned long long)st[1], (unsigned long long)c->ctg_cap);
+      rc = KC_ERR_CAPACITY;
+      break;
+    }
+    const uint64_t p1 = std::min<uint64_t>(len, p0 + (limit - st[1]));
+    const unsigned nblk = (unsigned)((p1 - p0 + 255) / 256);
+    switch (c->nl) {
+      case 1: hipLaunchKernelGGL(kc_ctg_insert_kernel<1>, dim3(nblk), dim3(256), 0, c->stream, d_seqs, d_depths, p0, p1, len, c->k, c->ctg_table, c->d_ctg_status, own); break;
+      case 2: hipLaunchKernelGGL(kc_ctg_insert_kernel<2>, dim3(nblk), dim3(256), 0, c->stream, d_seqs, d_depths, p0, p1, len, c->k, c->ctg_table, c->d_ctg_status, own); break;
+      case 3: hipLaunchKernelGGL(kc_ctg_insert_kernel<3>, dim3(nblk), dim3(256), 0, c->stream, d_seqs, d_depths, p0, p1, len, c->k, c->ctg_table, c->d_ctg_status, own); break;
+      default: hipLaunchKernelGGL(kc_ctg_insert_kernel<4>, dim3(nblk), dim3(256), 0, c->stream, d_seqs, d_depths, p0, p1, len, c->k, c->ctg_table, c->d_ctg_status, own); break;
+    }
+    c->num_gpu_calls++;
+    e = hipGetLastError();
+    if (e == hipSuccess) e = hipMemcpyAsync(st, c->d_ctg_status, 16, hipMemcpyDeviceToHost, c->stream);
+    if (e == hipSuccess) e = hipStreamSynchronize(c->stream);
+    if (e != hipSuccess) break;
+    c->ctg_new = st[1];
+    p0 = p1;
+  }
   if (tmp) (void)hipFree(tmp);
   if (e != hipSuccess) return hip_fail(e, "kc_submit_ctg_block", __LINE__);
+  if (rc) return rc;
   if (st[0]) return KC_ERR_BAD_BASE;
   c->ctg_attempted += len;
-  c->ctg_new = st[1];
-  if (st[1] * 4 > c->ctg_cap * 3) {
-    snprintf(g_last_error, sizeof(g_last_error), "contig pass: %llu distinct k-mers overfill the table kc_begin_ctg_kmers made (%llu slots)",
-             (unsigned long long)st[1], (unsigned long long)c->ctg_cap);
-    return KC_ERR_CAPACITY;
-  }
+  return KC_OK;
+}
+
+extern "C" int kc_arena_probe_rate(kc_ctx *c, double *tbps) {
+  if (!c || !tbps) return KC_ERR_INVALID_ARG;
+  *tbps = c->arena_probe_tbps;
+  return KC_OK;
+}
+
+extern "C" int kc_ctg_stats(kc_ctx *c, uint64_t *distinct, uint64_t *positions) {
+  if (!c) return KC_ERR_INVALID_ARG;
+  if (distinct) *distinct = c->ctg_new;
+  if (positions) *positions = c->ctg_attempted;
   return KC_OK;
 }
 

@@ -20,27 +20,40 @@
 // complement) and the extension pair (first writer sets it, anybody who differs marks the conflict) -- and kc_finalize
 // appends the k-mers that qualify and are not among the reads' results (the lookup index of kc_lookup finds those).
 #pragma once
+#include "kc_bucketed.hpp"
 #include "kc_supermer.hpp"
 
 namespace kc {
 
 constexpr uint32_t CTG_EXT_CONFLICT = 0xFFFFFFFFu;
 
-// One thread per position of a '_'-joined block of contigs (any case: a lower-case neighbour counts as low quality,
-// get_kmers_and_exts kcount_cpu.cpp:308-336); depths[p] = the depth of the contig position p belongs to (the layout of
-// SeqBlockInserterState::depth_block, kcount_gpu.cpp:74-91,160).  t.vals: two words per slot.
+// Which contig k-mers a context of several ranks keeps: the ones the read path would keep there (a caller that routes its
+// supermers by target, like the C++ driver, submits only those anyway).
+enum { CTG_OWN_ALL = 0, CTG_OWN_HASH, CTG_OWN_REFERENCE, CTG_OWN_BUCKET };
+struct CtgOwn {
+  uint32_t mode, rank_me, rank_n;
+  uint32_t own_lo, own_hi;  // CTG_OWN_BUCKET (the shard flow): the level-1 buckets this shard owns
+  Geom gm;
+};
+
+// One thread per position [p0, p1) of a '_'-joined block of contigs (any case: a lower-case neighbour counts as low
+// quality, get_kmers_and_exts kcount_cpu.cpp:308-336); depths[p] = the depth of the contig position p belongs to (the
+// layout of SeqBlockInserterState::depth_block, kcount_gpu.cpp:74-91,160).  t.vals: two words per slot.  The host keeps
+// the positions of a launch within the table's free room (kc_submit_ctg_block), so the probe loop of table_slot always
+// meets an empty slot.
 template <int NL>
-__global__ void kc_ctg_insert_kernel(const uint8_t *seqs, const uint16_t *depths, uint64_t len, int k, Table t, uint64_t *status) {
-  const uint64_t p = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
+__global__ void kc_ctg_insert_kernel(const uint8_t *seqs, const uint16_t *depths, uint64_t p0, uint64_t p1, uint64_t len, int k, Table t,
+                                     uint64_t *status, CtgOwn own) {
+  const uint64_t p = p0 + (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (p >= p1) return;
+  // the alphabet, position by position (every thread its own character, whatever becomes of its window): the reference
+  // DIEs on a character outside it (kcount_cpu.cpp:481-487)
+  if (seqs[p] != '_' && !sm_is_base(seqs[p])) status[0] = 1;
   if (p < 1 || p + k >= len) return;
-  for (int i = -1; i <= k; i++) {
-    const uint8_t c = seqs[p + i];
-    if (c == '_') return;  // the window of the k-mer and its two neighbours must lie inside one contig (S1, S5)
-    if (!sm_is_base(c)) {
-      status[0] = 1;  // the reference DIEs on such a character (kcount_cpu.cpp:481-487)
-      return;
-    }
-  }
+  for (int i = -1; i <= k; i++)
+    if (seqs[p + i] == '_') return;  // the window of the k-mer and its two neighbours must lie inside one contig (S1, S5)
+  for (int i = -1; i <= k; i++)
+    if (!sm_is_base(seqs[p + i])) return;  // (its own thread reports it)
   constexpr int KL = NL;  // key words (the contig table keeps the k-mer alone: no extension bits in its last word)
   uint64_t f[KL], r[KL];
 #pragma unroll
@@ -69,6 +82,21 @@ __global__ void kc_ctg_insert_kernel(const uint8_t *seqs, const uint16_t *depths
     re = r2;
 #pragma unroll
     for (int j = 0; j < KL; j++) f[j] = r[j];
+  }
+  if (own.mode != CTG_OWN_ALL) {  // f is the canonical k-mer now
+    uint32_t o;
+    if (own.mode == CTG_OWN_REFERENCE) {
+      uint64_t rr[KL];
+      kc_revcomp<KL>(f, k, rr);
+      o = kc_reference_owner<KL>(f, rr, k, own.rank_n);
+    } else if (own.mode == CTG_OWN_HASH) {
+      o = kc_owner_of_hash(kc_hash<KL>(f), own.rank_n);
+    } else {
+      const uint32_t b1 = (KL == 1 && own.gm.cp) ? (uint32_t)(kc_feistel_fwd(f[0] >> (64u - own.gm.k2), k) >> (own.gm.k2 - own.gm.la))
+                                                  : hash_b1(kc_hash<KL>(f), own.gm);
+      o = (b1 >= own.own_lo && b1 < own.own_hi) ? own.rank_me : own.rank_me + 1u;
+    }
+    if (o != own.rank_me) return;
   }
   bool is_new;
   const uint64_t slot = table_slot<KL>(t, f, is_new);

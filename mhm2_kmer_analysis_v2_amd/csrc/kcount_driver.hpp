@@ -218,7 +218,6 @@ class HashTableDriver {
     StopWatch sw;
     check(kc_submit_ctg_block(ctx, ctg_seqs.data(), ctg_depths.data(), ctg_seqs.size(), 0), "kc_submit_ctg_block");
     num_gpu_calls++;
-    ctg_stats.new_inserts += ctg_seqs.size();
     ctg_seqs.clear();
     ctg_depths.clear();
     t_insert += sw.stop();
@@ -366,8 +365,10 @@ class HashTableDriver {
   void done_ctg_kmer_inserts(uint64_t &attempted, uint64_t &dropped, uint64_t &new_inserts) {
     flush_ctg_block();
     attempted = ctg_stats.attempted;
-    dropped = 0;
-    new_inserts = ctg_stats.new_inserts;
+    dropped = 0;  // (the contig table never drops: a block that does not fit ends in KC_ERR_CAPACITY)
+    uint64_t distinct = 0;
+    check(kc_ctg_stats(ctx, &distinct, nullptr), "kc_ctg_stats");
+    new_inserts = ctg_stats.new_inserts = distinct;  // the distinct contig k-mers this rank's table took
   }
 
   // gpu_hash_table.cpp:736-784: purge + compact + copy back

@@ -187,6 +187,12 @@ class KmerCounter:
         blk = np.frombuffer(block, dtype=np.uint8)
         check(lib().kc_submit_ctg_block(self._h, blk.ctypes.data, dd.ctypes.data, len(blk), 0), "kc_submit_ctg_block")
 
+    def ctg_stats(self):
+        """(distinct contig k-mers in the contig table, characters submitted)"""
+        d, n = C.c_uint64(0), C.c_uint64(0)
+        check(lib().kc_ctg_stats(self._h, C.byref(d), C.byref(n)), "kc_ctg_stats")
+        return int(d.value), int(n.value)
+
     def submit_packed_supermers(self, packed):
         """4-bit packed supermers joined by the byte '_' (HashTableGPUDriver::insert_supermer's buffer)."""
         pp, dev = _ptr(packed)
@@ -299,6 +305,12 @@ class KmerCounter:
         s = kc_stats()
         check(lib().kc_get_stats(self._h, C.byref(s)), "kc_get_stats")
         return {n: int(getattr(s, n)) for n, _ in kc_stats._fields_}
+
+    def arena_probe_rate(self):
+        """TB/s of level 1's write pattern on the level-1 arena this context chose (0.0: no probe ran)."""
+        v = C.c_double(0.0)
+        check(lib().kc_arena_probe_rate(self._h, C.byref(v)), "kc_arena_probe_rate")
+        return float(v.value)
 
     def kernel_times(self, clear=False):
         """{kernel name: (launches, total_ms)} from HIP events on the launch stream (needs time_kernels=True)."""

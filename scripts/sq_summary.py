@@ -3,7 +3,7 @@ python scripts/sq_summary.py gpurun_out/pmc_sq/runc/N_counter_collection.csv gpu
 Only the FIRST dispatch of each hot kernel after the warm-up is taken for the split kernels (one launch of level 2 and of
 the count kernel is a whole step; level 1's launches of the step are summed)."""
 import csv, sys, collections
-HOT = ("kc_l1_reads16_kernel", "kc_l1_reads_kernel", "kc_l2_pairs_kernel", "kc_l2_split_kernel", "kc_count_kernel")
+HOT = ("kc_l1_reads16_kernel", "kc_l1_reads_kernel", "kc_l2_split_kernel", "kc_count_kernel")
 agg = collections.defaultdict(lambda: collections.defaultdict(float))
 ndisp = collections.defaultdict(set)
 for f in sys.argv[1:]:
@@ -17,7 +17,7 @@ wave_records = 6.5e9 / 64
 for k in HOT:
     v = agg[k]
     nd = max(len(s) for (kk, f), s in ndisp.items() if kk == k)
-    steps = nd / (5 if k == "kc_l1_reads_kernel" else 1)   # the stage step and the end-to-end legs run the same kernels
+    steps = nd / (5 if "l1_reads" in k else 1)   # the stage step and the end-to-end legs run the same kernels
     print("%s: %d dispatches = %.0f passes over 50 M reads" % (k, nd, steps))
     per = lambda c: v.get(c, 0) / steps / wave_records
     print("   per 64 k-mers: VALU %.1f  SALU %.1f  LDS %.1f  VMEM read %.2f  VMEM write %.2f  SMEM %.2f" %

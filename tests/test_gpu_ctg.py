@@ -107,3 +107,87 @@ def test_contig_pass_errors():
         with pytest.raises(pkg.KcError) as e:  # a character the reference DIEs on
             kc.submit_ctgs(["ACGT" * 10 + "X" + "ACGT" * 10], [5])
         assert e.value.status == -7
+
+
+def test_a_contig_table_that_is_too_small_reports_capacity_and_never_spins():
+    """kc_begin_ctg_kmers sized from an estimate that is far too low: a block with more distinct k-mers than the table has
+    slots must come back with KC_ERR_CAPACITY (launches are bounded by the table's free room), not hang in a probe loop."""
+    k = 21
+    rng = np.random.default_rng(77)
+    ctg = "".join(rng.choice(list("ACGT"), size=6000))  # ~6000 distinct k-mers
+    with pkg.KmerCounter(k) as kc:
+        kc.begin_ctg_kmers(10)  # -> 1024 slots
+        with pytest.raises(pkg.KcError) as e:
+            kc.submit_ctgs([ctg], [5])
+        assert e.value.status == -6  # KC_ERR_CAPACITY
+        distinct, _ = kc.ctg_stats()
+        assert 0 < distinct <= 1024 * 3 // 4
+    # a table with room takes the same block in one go, and one that is only just large enough takes it in several launches
+    for room in (8000, 3000):
+        with pkg.KmerCounter(k) as kc:
+            kc.begin_ctg_kmers(room)
+            kc.submit_ctgs([ctg], [5])
+            distinct, positions = kc.ctg_stats()
+            assert distinct == len({min(ctg[i:i + k], ctg[i:i + k][::-1].translate(str.maketrans("ACGT", "TGCA"))) for i in range(1, len(ctg) - k)})
+            assert positions == len(ctg) + 1
+
+
+def test_a_bad_character_is_seen_wherever_it_sits():
+    """The reference DIEs on any character outside ACGTN (kcount_cpu.cpp:481-487): also in a contig shorter than k + 2 and
+    within k + 1 of a contig's end, where no k-mer window reaches it."""
+    k = 21
+    for ctgs in (["ACGTX"], ["ACGT" * 20, "ACG", "AC!T" + "A" * 5], ["ACGT" * 20 + "Z"], ["Z" + "ACGT" * 20]):
+        with pkg.KmerCounter(k) as kc:
+            kc.begin_ctg_kmers(1000)
+            with pytest.raises(pkg.KcError) as e:
+                kc.submit_ctgs(ctgs, [5] * len(ctgs))
+            assert e.value.status == -7  # KC_ERR_BAD_BASE
+
+
+@pytest.mark.parametrize("mode", ["hash", "reference", "shard-flow"])
+@pytest.mark.parametrize("k", [21, 51])
+def test_contig_pass_of_several_ranks_keeps_every_kmer_exactly_once(k, mode):
+    """rank_n > 1: every rank is given every read and every contig; each keeps its own share (the read path's owner test),
+    and the union of the ranks' results is the oracle's single answer -- no k-mer twice, none with a contig's depth where
+    another rank's reads kept it."""
+    rng = np.random.default_rng(1300 + k)
+    genome = "".join(rng.choice(list("ACGT"), size=3000))
+    reads, quals = [], []
+    for _ in range(700):
+        a = int(rng.integers(0, len(genome) - 160))
+        ln = int(rng.integers(k + 2, 150))
+        reads.append(genome[a:a + ln])
+        quals.append("I" * ln)
+    b, q, offs = arrays(reads, quals)
+    ctgs, depths = make_ctgs(rng, genome, k)
+    o = O.Oracle(k, nranks=3, nthreads=1)
+    o.add_reads(b, q, offs)
+    for c, d in zip(ctgs, depths):
+        o.add_ctg(c, d)
+    want = o.finalize()
+    o.close()
+    R = 3
+    parts = []
+    if mode == "shard-flow":
+        # every shard extracts its slice of the reads and ships the buckets it does not own; then every shard is given
+        # every contig and keeps the k-mers of its own buckets
+        from test_gpu_shard_flow import run_shards
+        shards, _, _ = run_shards(reads, quals, k, R, None)
+        for s in shards:
+            s.begin_ctg_kmers(sum(len(c) for c in ctgs))
+            s.submit_ctgs(ctgs, depths)
+            parts.append(s.sorted_results())
+            s.close()
+    else:
+        for r in range(R):
+            with pkg.KmerCounter(k, rank_me=r, rank_n=R, reference_owner=(mode == "reference")) as kc:
+                kc.submit_reads(b, q, offs)
+                kc.begin_ctg_kmers(sum(len(c) for c in ctgs))
+                kc.submit_ctgs(ctgs, depths)
+                parts.append(kc.sorted_results())
+    keys = np.concatenate([p[0] for p in parts])
+    cnt = np.concatenate([p[1] for p in parts])
+    lf = np.concatenate([p[2] for p in parts])
+    rt = np.concatenate([p[3] for p in parts])
+    order = np.lexsort([keys[:, j] for j in range(keys.shape[1] - 1, -1, -1)])
+    assert_same((keys[order], cnt[order], lf[order], rt[order]), want)

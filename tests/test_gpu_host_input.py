@@ -134,3 +134,29 @@ def test_level_2_in_instalments_equals_level_2_at_once(small_blocks, monkeypatch
         for g, w in zip(got[inst], want):
             assert g.shape == w.shape and (g == w).all()
         assert st["num_unique"] == wst["unique"] and st["sum_counts"] == wst["sum_counts"]
+
+
+@pytest.mark.parametrize("shift", [1, 7, 16, 100])
+def test_pinned_arrays_of_different_alignment_keep_the_wide_loads(small_blocks, shift):
+    """Bases and qualities in two pinned buffers whose starts differ modulo 16: every block's copy starts on a page of ITS
+    source, so the two leads differ modulo 16 -- the qualities are then placed up to 15 bytes further into their device
+    slot, a read's bases and qualities stay co-aligned, and level 1 runs its 16-byte-load instantiation for every block
+    (it used to fall back, silently, to byte-loaded qualities)."""
+    import torch
+    k = 21
+    b, q, offs, want, _ = _input(k, seed=8)
+    pb = torch.empty(len(b) + 4096, dtype=torch.uint8).pin_memory()
+    pq = torch.empty(len(q) + 4096, dtype=torch.uint8).pin_memory()
+    bb = pb.numpy()[:len(b)]
+    qq = pq.numpy()[shift:shift + len(q)]
+    bb[:] = b
+    qq[:] = q
+    assert (bb.ctypes.data - qq.ctypes.data) % 16 == (-shift) % 16
+    with pkg.KmerCounter(k, time_kernels=True) as kc:
+        kc.submit_reads(bb, qq, offs)
+        got = kc.sorted_results()
+        names = set(kc.kernel_times())
+    for g, w in zip(got, want):
+        assert g.shape == w.shape and (g == w).all()
+    assert any(n.startswith("kc_l1_reads") for n in names)
+    assert not any("byte-loaded" in n for n in names), names

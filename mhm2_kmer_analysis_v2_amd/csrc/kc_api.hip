@@ -811,6 +811,8 @@ static int bk_init(kc_ctx *c) {
     if (!rc) rc = bk_take(c, 2, (void **)&b.cnt1, nseg * 4);
     if (!rc) rc = bk_take(c, 3, (void **)&b.used1, (size_t)g.G * 2 * 4);
     if (!rc) rc = bk_take(c, 4, (void **)&b.rec2, rec2_bytes, &rec2_reused);
+    // (level 2's arena chosen the same way -- its ratio does not predict level 2's time, and what level 1 gains on an
+    // arena with a high ratio level 2, which reads that arena, loses again: profiles/r04_arena_selection.txt, section E)
     if (!rc) rc = bk_take(c, 5, (void **)&b.chain2, (size_t)R * g.L2MAX * 4);
     if (!rc) rc = bk_take(c, 6, (void **)&b.cnt2, (size_t)R * 4);
     if (!rc) rc = bk_take(c, 7, (void **)&b.base2, ((size_t)g.P1 + 1) * 4);

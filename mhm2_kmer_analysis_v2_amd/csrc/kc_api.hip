@@ -145,8 +145,8 @@ struct kc_ctx {
   struct {
     bool flow;         // this pass runs the shard flow (kc_shard_extract / kc_shard_commit were used)
     bool extracting;   // inside kc_shard_extract: level 1 keeps every k-mer, whoever owns it
-    uint64_t *d_plan;  // off[PMAX], totals[SHARD_MAX], flags[SHARD_MAX], loose[SHARD_MAX]
-    uint64_t *h_plan;  // pinned mirror of totals, flags, loose (+ SHARD_MAX header words)
+    uint64_t *d_plan;  // off[PMAX], totals[SHARD_MAX], flags[SHARD_MAX], loose[SHARD_MAX], wtotals[SHARD_MAX]
+    uint64_t *h_plan;  // pinned mirror of totals, flags, loose, wtotals (+ SHARD_MAX header words)
     uint32_t F;        // flat sources (received segments) of this pass
     uint32_t nbo;      // buckets this shard owns (row length of d_cnt / d_at)
     uint32_t *d_cnt;   // [FLAT_MAX][nbo]
@@ -1879,8 +1879,8 @@ static uint64_t shard_signature(const kc_ctx *c) {
 
 static int shard_init(kc_ctx *c) {
   if (c->sh.d_plan) return KC_OK;
-  HIPCHK(hipMalloc((void **)&c->sh.d_plan, ((size_t)PMAX + 3 * SHARD_MAX) * 8));
-  HIPCHK(hipHostMalloc((void **)&c->sh.h_plan, (size_t)4 * SHARD_MAX * 8, hipHostMallocDefault));
+  HIPCHK(hipMalloc((void **)&c->sh.d_plan, ((size_t)PMAX + 4 * SHARD_MAX) * 8));
+  HIPCHK(hipHostMalloc((void **)&c->sh.h_plan, (size_t)5 * SHARD_MAX * 8, hipHostMallocDefault));
   return KC_OK;
 }
 
@@ -1888,16 +1888,17 @@ template <int NL>
 static void launch_shard_pack(kc_ctx *c, uint64_t *segs, uint64_t seg_words, const uint64_t *off, const uint64_t *flags) {
   const uint32_t Q = 4;  // workgroups per bucket
   KernelTimer kt(c, KT_SHARD_PACK);
-  hipLaunchKernelGGL(kc_shard_pack_kernel<NL>, dim3(c->gm.P1 * Q), dim3(WGB), 0, c->stream, c->gm, c->bb, (uint32_t)c->cfg.rank_me,
-                     (uint32_t)c->cfg.rank_n, segs, seg_words, off, flags, Q);
+  auto kern = (NL == 1 && shard_wire_of(c->gm) == SHARD_WIRE_COMPACT) ? kc_shard_pack_kernel<NL, NL == 1> : kc_shard_pack_kernel<NL, false>;
+  hipLaunchKernelGGL(kern, dim3(c->gm.P1 * Q), dim3(WGB), 0, c->stream, c->gm, c->bb, (uint32_t)c->cfg.rank_me, (uint32_t)c->cfg.rank_n, segs,
+                     seg_words, off, flags, Q);
 }
 
 template <int NL>
-static void launch_shard_route(kc_ctx *c, uint64_t n1, uint64_t *segs, uint64_t seg_words, const uint64_t *totals, uint64_t *loose, uint64_t *flags) {
+static void launch_shard_route(kc_ctx *c, uint64_t n1, uint64_t *segs, uint64_t seg_words, const uint64_t *wtotals, uint64_t *loose, uint64_t *flags) {
   auto kern = use_cp<NL>(c) ? kc_shard_route_ovf1_kernel<NL, NL == 1> : kc_shard_route_ovf1_kernel<NL, false>;
   KernelTimer kt(c, KT_FALLBACK);
   hipLaunchKernelGGL(kern, dim3((unsigned)std::min<uint64_t>((n1 + TPB - 1) / TPB, 256 * 32)), dim3(TPB), 0, c->stream, c->gm, c->bb, n1,
-                     (uint32_t)c->cfg.rank_me, (uint32_t)c->cfg.rank_n, segs, seg_words, totals, loose, flags, c->table, c->d_ctrs);
+                     (uint32_t)c->cfg.rank_me, (uint32_t)c->cfg.rank_n, segs, seg_words, wtotals, loose, flags, c->table, c->d_ctrs);
 }
 
 template <int NL>
@@ -1940,10 +1941,10 @@ static int shard_extract_pack(kc_ctx *c, bool anything, uint64_t *d_segments, ui
   if (n == 1 || !anything) return KC_OK;  // a single shard owns every bucket: nothing leaves
   rc = shard_init(c);
   if (rc) return rc;
-  uint64_t *off = c->sh.d_plan, *totals = off + PMAX, *flags = totals + SHARD_MAX, *loose = flags + SHARD_MAX;
+  uint64_t *off = c->sh.d_plan, *totals = off + PMAX, *flags = totals + SHARD_MAX, *loose = flags + SHARD_MAX, *wtotals = loose + SHARD_MAX;
   HIPCHK(hipMemsetAsync(loose, 0, SHARD_MAX * 8, c->stream));
   hipLaunchKernelGGL(kc_shard_plan_kernel, dim3(1), dim3(WGB), 0, c->stream, c->gm, c->bb, me, n, d_segments, seg_words, shard_signature(c),
-                     (uint32_t)c->nl, off, totals, flags);
+                     (uint32_t)c->nl, off, totals, flags, wtotals);
   switch (c->nl) {
     case 1: launch_shard_pack<1>(c, d_segments, seg_words, off, flags); break;
     case 2: launch_shard_pack<2>(c, d_segments, seg_words, off, flags); break;
@@ -1964,10 +1965,10 @@ static int shard_extract_pack(kc_ctx *c, bool anything, uint64_t *d_segments, ui
     rc = ensure_room(c, n1);
     if (rc) return rc;
     switch (c->nl) {
-      case 1: launch_shard_route<1>(c, n1, d_segments, seg_words, totals, loose, flags); break;
-      case 2: launch_shard_route<2>(c, n1, d_segments, seg_words, totals, loose, flags); break;
-      case 3: launch_shard_route<3>(c, n1, d_segments, seg_words, totals, loose, flags); break;
-      default: launch_shard_route<4>(c, n1, d_segments, seg_words, totals, loose, flags); break;
+      case 1: launch_shard_route<1>(c, n1, d_segments, seg_words, wtotals, loose, flags); break;
+      case 2: launch_shard_route<2>(c, n1, d_segments, seg_words, wtotals, loose, flags); break;
+      case 3: launch_shard_route<3>(c, n1, d_segments, seg_words, wtotals, loose, flags); break;
+      default: launch_shard_route<4>(c, n1, d_segments, seg_words, wtotals, loose, flags); break;
     }
     HIPCHK(hipGetLastError());
     HIPCHK(hipMemsetAsync(c->d_cb + CB_OVF1, 0, 8, c->stream));
@@ -1979,10 +1980,10 @@ static int shard_extract_pack(kc_ctx *c, bool anything, uint64_t *d_segments, ui
     c->num_gpu_calls++;
   }
   HIPCHK(hipGetLastError());
-  HIPCHK(hipMemcpyAsync(c->sh.h_plan, totals, (size_t)3 * SHARD_MAX * 8, hipMemcpyDeviceToHost, c->stream));
+  HIPCHK(hipMemcpyAsync(c->sh.h_plan, totals, (size_t)4 * SHARD_MAX * 8, hipMemcpyDeviceToHost, c->stream));
   HIPCHK(hipStreamSynchronize(c->stream));
-  const uint64_t *h_totals = c->sh.h_plan, *h_flags = h_totals + SHARD_MAX, *h_loose = h_flags + SHARD_MAX;
-  uint64_t *h_hdr = c->sh.h_plan + 3 * SHARD_MAX;
+  const uint64_t *h_totals = c->sh.h_plan, *h_flags = h_totals + SHARD_MAX, *h_loose = h_flags + SHARD_MAX, *h_wtotals = h_loose + SHARD_MAX;
+  uint64_t *h_hdr = c->sh.h_plan + 4 * SHARD_MAX;
   bool patched = false;
   for (uint32_t d = 0; d < n; d++) {
     if (d == me) continue;
@@ -1992,7 +1993,7 @@ static int shard_extract_pack(kc_ctx *c, bool anything, uint64_t *d_segments, ui
       return KC_ERR_CAPACITY;
     }
     const uint32_t nb = shard_first_bucket(d + 1, c->gm.P1, n) - shard_first_bucket(d, c->gm.P1, n);
-    h_words[d] = shard_header_words(nb) + (h_totals[d] + h_loose[d]) * (uint64_t)c->nl;
+    h_words[d] = shard_header_words(nb) + h_wtotals[d] + h_loose[d] * (uint64_t)c->nl;  // (five bytes a record in the compact wire form)
     if (h_loose[d]) {
       h_hdr[d] = (uint64_t)nb | (h_loose[d] << 32);
       HIPCHK(hipMemcpyAsync(d_segments + (size_t)d * seg_words + 1, &h_hdr[d], 8, hipMemcpyHostToDevice, c->stream));
@@ -2081,8 +2082,10 @@ extern "C" int kc_shard_commit(kc_ctx *c, const uint64_t *d_segment, uint64_t nw
   HIPCHK(hipStreamSynchronize(c->stream));
   const uint32_t lo = shard_first_bucket(me, c->gm.P1, n), nbo = shard_first_bucket(me + 1, c->gm.P1, n) - lo;
   const uint32_t nb = (uint32_t)hdr[1];
-  const uint64_t loose = hdr[1] >> 32, nrec = hdr[2];
-  if (hdr[0] != shard_signature(c) || nb != nbo || shard_header_words(nb) + (nrec + loose) * (uint64_t)c->nl != nwords) {
+  const uint64_t loose = hdr[1] >> 32, nrec = hdr[2], rec_words = hdr[3] & ((1ULL << 56) - 1);
+  const uint32_t wire = (uint32_t)(hdr[3] >> 56);
+  if (hdr[0] != shard_signature(c) || nb != nbo || wire != shard_wire_of(c->gm) ||
+      shard_header_words(nb) + rec_words + loose * (uint64_t)c->nl != nwords) {
     snprintf(g_last_error, sizeof(g_last_error), "kc_shard_commit: not a segment for this shard (made by a context with another k, geometry or shard count?)");
     return KC_ERR_INVALID_ARG;
   }
@@ -2091,11 +2094,15 @@ extern "C" int kc_shard_commit(kc_ctx *c, const uint64_t *d_segment, uint64_t nw
     // them, and a truncated or corrupt segment would otherwise be read past its end at finalize
     std::vector<uint32_t> counts(nb);
     HIPCHK(hipMemcpy(counts.data(), d_segment + SHARD_HDR, (size_t)nb * 4, hipMemcpyDeviceToHost));
-    uint64_t sum = 0;
-    for (uint32_t v : counts) sum += v;
-    if (sum != nrec) {
-      snprintf(g_last_error, sizeof(g_last_error), "kc_shard_commit: the segment's bucket counts add up to %llu records, its header says %llu",
-               (unsigned long long)sum, (unsigned long long)nrec);
+    uint64_t sum = 0, wsum = 0;
+    for (uint32_t v : counts) {
+      sum += v;
+      wsum += shard_bucket_words(v, (uint32_t)c->nl, wire);
+    }
+    if (sum != nrec || wsum != rec_words) {
+      snprintf(g_last_error, sizeof(g_last_error),
+               "kc_shard_commit: the segment's bucket counts add up to %llu records in %llu words, its header says %llu in %llu",
+               (unsigned long long)sum, (unsigned long long)wsum, (unsigned long long)nrec, (unsigned long long)rec_words);
       return KC_ERR_INVALID_ARG;
     }
   }
@@ -2119,14 +2126,14 @@ extern "C" int kc_shard_commit(kc_ctx *c, const uint64_t *d_segment, uint64_t nw
   c->sh.flow = true;
   c->started = true;
   const uint32_t f = c->sh.F++;
-  hipLaunchKernelGGL(kc_shard_index_kernel, dim3(1), dim3(WGB), 0, c->stream, d_segment, nb, (uint32_t)c->nl, c->sh.d_cnt + (size_t)f * nbo,
+  hipLaunchKernelGGL(kc_shard_index_kernel, dim3(1), dim3(WGB), 0, c->stream, d_segment, nb, (uint32_t)c->nl, wire, c->sh.d_cnt + (size_t)f * nbo,
                      c->sh.d_at + (size_t)f * nbo, c->d_ctrs);
   c->num_gpu_calls++;
   HIPCHK(hipGetLastError());
   if (loose) {
     rc = ensure_room(c, loose);
     if (rc) return rc;
-    const uint64_t *lp = d_segment + shard_header_words(nb) + nrec * (uint64_t)c->nl;
+    const uint64_t *lp = d_segment + shard_header_words(nb) + rec_words;
     switch (c->nl) {
       case 1: launch_shard_loose<1>(c, lp, loose); break;
       case 2: launch_shard_loose<2>(c, lp, loose); break;

@@ -1203,6 +1203,7 @@ __global__ __launch_bounds__(WGB) void kc_bucket_prefix_kernel(Geom gm, BucketBu
 }
 
 // ---- level 2 ------------------------------------------------------------------------------------------
+typedef uint64_t __attribute__((aligned(1))) U64Unaligned;  // an 8-byte load from any byte address (one instruction on gfx950)
 struct L2LDS {
   SplitLDS sp;
   uint32_t pre[GMAX + 1];  // prefix of the bucket's G segment lengths (+ those of its flat sources)
@@ -1280,6 +1281,7 @@ __global__ __launch_bounds__(WGB) void kc_l2_split_kernel(Geom gm, BucketBufs bb
     // round trips per round (fetched pairwise, every record load would wait for its own id load: sixteen in a row).
     uint32_t p_ids = 0, p_rec = 0;  // segment cursors of this thread, one per pass (their indices only grow)
     uint64_t nxt[RPOS][NL];
+    uint32_t nxt_flat = 0;  // FL && CR: bit j = nxt[j] came from a flat source (wire form)
     const uint32_t CH1m = (1u << gm.log2CH1) - 1u;
     // no branches around the loads (a lane past the end re-reads the bucket's last record): a load inside a
     // conditional block is waited for at the end of that block
@@ -1300,6 +1302,15 @@ __global__ __launch_bounds__(WGB) void kc_l2_split_kernel(Geom gm, BucketBufs bb
         const uint64_t *src = bb.rec1 + (((((size_t)p_rec * gm.A1) + ids[j]) << gm.log2CH1) + ((e - L.pre[p_rec] + (INC ? L.skip[p_rec] : 0u)) & CH1m)) * NL;
         if constexpr (FL) {
           const uint64_t f0 = L.flo[p_rec >= G ? p_rec - G : 0u];
+          if constexpr (CR) {
+            // a flat source of short-form records is in the five-byte wire form (kc_shard.hpp): the record's bytes and
+            // up to three behind it in ONE unaligned 8-byte load (a bucket's block ends with that much to spare); which
+            // of its records a thread took from flat sources it remembers in a bit each
+            if (p_rec >= G) src = reinterpret_cast<const uint64_t *>((uintptr_t)f0 + 5u * (size_t)(e - L.pre[p_rec]));
+            nxt_flat = p_rec >= G ? (nxt_flat | (1u << j)) : (nxt_flat & ~(1u << j));
+            nxt[j][0] = *reinterpret_cast<const U64Unaligned *>(src);
+            continue;
+          }
           if (p_rec >= G) src = reinterpret_cast<const uint64_t *>((uintptr_t)f0) + (size_t)(e - L.pre[p_rec]) * NL;
         }
 #pragma unroll
@@ -1316,8 +1327,15 @@ __global__ __launch_bounds__(WGB) void kc_l2_split_kernel(Geom gm, BucketBufs bb
 #pragma unroll
       for (int j = 0; j < RPOS; j++) {
         if constexpr (CR) {
-          lo[j] = (uint32_t)(nxt[j][0] >> (64u - gm.k2));
-          br[j] = ((lo[j] >> sh_b2) & (P2 - 1u)) | (((uint32_t)nxt[j][0] & 63u) << 10);
+          uint32_t ext;
+          if (FL && ((nxt_flat >> j) & 1u)) {  // wire form: the 32 bits below the bucket, then the extension bits in a byte
+            lo[j] = (uint32_t)nxt[j][0];
+            ext = (uint32_t)(nxt[j][0] >> 32) & 63u;
+          } else {
+            lo[j] = (uint32_t)(nxt[j][0] >> (64u - gm.k2));
+            ext = (uint32_t)nxt[j][0] & 63u;
+          }
+          br[j] = ((lo[j] >> sh_b2) & (P2 - 1u)) | (ext << 10);
         } else {
 #pragma unroll
           for (int w = 0; w < NL; w++) rec[j][w] = nxt[j][w];

@@ -20,9 +20,12 @@
 //
 // Two send buffers alternate, so block i travels while block i+1 is extracted.  Nothing else is communicated: ownership
 // is a pure function of the k-mer (kc_shard_owner / kc_owner), finalize is per shard.
-// xGMI is point to point: every rank ships 1/N of its records to each peer over that peer's own link; at 8 bytes per
-// k-mer and the rate one GPU extracts at (~45 G k-mers/s) that is ~45 GB/s per link, within a link's ~75 GB/s per
-// direction but not negligible -- hence the side stream.
+// xGMI is point to point: every rank ships 1/N of its records to each peer over that peer's own link (76.8 GB/s a
+// direction at its peak).  At the rate one GPU's kernels run (50 M reads = 6.4 G records in ~72 ms) the links are what
+// bounds an 8-shard stage if a record travels as its 8-byte word: 7/8 x 6.4 G x 8 B = 44.8 GB per step and shard = 6.4 GB
+// per link = 83 ms.  So the BUCKETS flow ships the compact records of k=21 as FIVE bytes (kc_shard.hpp,
+// SHARD_WIRE_COMPACT: 4.0 GB per link = 52 ms, under the kernels' time and overlapped with it on the side stream); longer
+// k-mers and the RECORDS flow ship whole words (DESIGN.md section 6 has the link budget for N = 2, 4, 8).
 //
 // Header-only over the C ABI (include/kcount_mi355.h) and <rccl/rccl.h>; no exceptions (MHM2 calls this inside UPC++
 // progress): every method returns a KC_* status, last_error() has the text.  The Python twin used by bench.py and the

@@ -213,6 +213,7 @@ def test_single_pass_shard_flow_at_size(k, R):
         do = torch.empty(nreads + 1, dtype=torch.int64, device="cuda")
         shards[r].synth_reads_device(db, dq, do, nreads, first_read=r * nreads, params=p)
         data.append((db, dq, do))
+    shipped_words = shipped_records = segments = 0
     for r0 in range(0, nreads, blk):
         r1 = min(nreads, r0 + blk)
         for r in range(R):
@@ -225,7 +226,18 @@ def test_single_pass_shard_flow_at_size(k, R):
                 dst = shards[d].shard_reserve(w)
                 dst.copy_(segs[d * seg_words:d * seg_words + w])
                 torch.cuda.synchronize()
+                shipped_words += w
+                shipped_records += int(dst[2].item())  # the header's record count
+                segments += 1
                 shards[d].shard_commit(dst, w)
+    # what crosses the links: the compact records of k=21 travel as five bytes each (kc_shard.hpp, SHARD_WIRE_COMPACT),
+    # longer k-mers as their words; beside them a header and less than two words of padding per bucket and segment
+    assert shipped_records > 0.9 * (R - 1) / R * R * nreads * (L - k - 1)
+    per_seg = 4 + 1024 // R // 2 + 2 + 2 * (1024 // R + 1)
+    if k == 21:
+        assert shipped_words * 8 <= 5 * shipped_records + 8 * per_seg * segments
+    else:
+        assert shipped_words <= nl * shipped_records + per_seg * segments
     x, s, n, uniq, sumc, ins = 0, 0, 0, 0, 0, 0
     for sh in shards:
         c = checksum(sh)

@@ -23,6 +23,7 @@ def run_shards(reads, quals, k, R, tuning, blocks=2, max_kmers_buffered=0, time_
     segs = torch.zeros(R * seg_words, dtype=torch.int64, device="cuda")
     per = (len(reads) + R - 1) // R
     shipped = 0
+    run_shards.records = run_shards.segments = 0  # (of the last call: foreign records shipped and the segments they travelled in)
     for blk in range(blocks):
         for r in range(R):
             mine = list(range(r * per, min(len(reads), (r + 1) * per)))
@@ -39,6 +40,8 @@ def run_shards(reads, quals, k, R, tuning, blocks=2, max_kmers_buffered=0, time_
                 torch.cuda.synchronize()  # the copy ran on torch's stream, the contexts have streams of their own
                 shards[d].shard_commit(dst, w)
                 shipped += w
+                run_shards.records += int(dst[2].item()) + (int(dst[1].item()) >> 32)  # header: records, loose records
+                run_shards.segments += 1
     return shards, shipped, total
 
 
@@ -62,6 +65,11 @@ def test_shard_flow_matches_oracle(k, R, path):
     want, _, wst = oracle_run(b, q, offs, k)
     shards, shipped, total = run_shards(reads, quals, k, R, PATHS[path])
     assert shipped > 0
+    # words on the wire per foreign record: five bytes in the compact wire form (short-form compact records: k=21 with
+    # 1024 level-1 buckets), the record's words otherwise -- plus header and padding per segment and bucket
+    P1 = (PATHS[path] or {}).get("p1", 0)
+    if path == "compact-short":
+        assert shipped * 8 <= 5 * run_shards.records + run_shards.segments * 8 * (4 + P1 // 2 + 2 * P1 + 4)
     parts = [s.sorted_results() for s in shards]
     assert_same(union(parts), want)
     st = [s.stats() for s in shards]

@@ -130,6 +130,9 @@ struct kc_ctx {
   bool inc_on;           // level 2 has begun in instalments (kc_l2_split_kernel<..., INC>): bb.done1 / used2 / cnt2 carry its state
   uint64_t *d_cb, *h_cb;
   bool bk_spilled;       // earlier buffer-fulls of this pass were counted and merged into the global table (bk_spill_pass)
+  bool l1_dropped;       // earlier buffer-fulls of this pass went through level 2 and left level 1 (bk_light_spill): level 2 holds them
+  uint64_t l2_held;      // ... that many records (an upper bound)
+  uint64_t l2_per_bucket;  // records every bucket's part of the level-2 arena has room for while level 2 runs in instalments
   uint64_t expect_base;  // CTR_EXPECT when the buffer was last emptied: what is buffered now is CTR_EXPECT - expect_base
   uint64_t expect_prev;  // CTR_EXPECT after the previous block
   uint64_t bk_capacity;  // records the level-1 segments are sized for
@@ -543,9 +546,12 @@ extern "C" int kc_reset(kc_ctx *c, int new_k) {
     }
   }
   c->inc_on = false;
+  c->l2_per_bucket = 0;
   HIPCHK(hipMemsetAsync(c->d_cb, 0, CB_COUNT * 8, c->stream));
   c->bk_level2 = c->bk_flagged = c->table_mode = c->started = false;
   c->bk_spilled = false;
+  c->l1_dropped = false;
+  c->l2_held = 0;
   c->expect_base = c->expect_prev = 0;
   c->expect_host = 0;
   c->expect_host_ok = true;
@@ -780,6 +786,10 @@ static int bk_init(kc_ctx *c) {
   // chains may grow to several times the mean: k-mer multiplicities are heavy-tailed
   g.L1MAX = t.chain1_max ? t.chain1_max : (uint32_t)(4.0 * mean1 / (double)CH1) + 8;
   g.L2MAX = std::min<uint32_t>(CHAIN_LDS, t.chain2_max ? t.chain2_max : (uint32_t)(4.0 * mean2 / (double)CH2) + 8);
+  // compact records: a region's chain has room for as many records as the count kernel takes at all (65535), so that a
+  // buffer that is smaller than the input can hand its records on to level 2 and start again (bk_light_spill): the
+  // regions then hold the whole input's records, not a buffer's
+  if (g.cp && !t.chain2_max) g.L2MAX = std::min<uint32_t>(CHAIN_LDS, std::max<uint32_t>(g.L2MAX, (uint32_t)((KC_COUNT_MAX + CH2) / CH2) + 1));
   g.A1 = t.arena1 ? t.arena1 : (uint32_t)(1.03 * (double)bcap / ((double)g.G * (double)CH1)) + g.P1 + 16;
   const uint64_t a2 = bcap / CH2 + R + g.P1 + 16;
   if (a2 >= (1ULL << 32) || (uint64_t)g.A1 * g.G >= (1ULL << 32) || bcap / g.P1 >= (1ULL << 31)) return KC_ERR_INVALID_ARG;
@@ -824,6 +834,7 @@ static int bk_init(kc_ctx *c) {
     if (rc) return rc;
   }
   c->inc_on = false;
+  c->l2_per_bucket = 0;
   HIPCHK(hipMemsetAsync(b.cnt1, 0, nseg * 4, c->stream));
   HIPCHK(hipMemsetAsync(b.used1, 0, (size_t)g.G * 2 * 4, c->stream));
   HIPCHK(hipMemsetAsync(b.cnt2, 0, (size_t)R * 4, c->stream));
@@ -1066,8 +1077,14 @@ static int bk_drain_t(kc_ctx *c) {
 }
 
 // The buffer is full: move everything buffered into the global table and stay on the table path.
+static int bk_spill_pass(kc_ctx *c);
 static int bk_drain_to_table(kc_ctx *c) {
-  int rc = sync_ctrs(c);
+  int rc;
+  if (c->l1_dropped) {  // level 2 holds records that level 1 no longer has: count them and merge them into the table first
+    rc = bk_spill_pass(c);
+    if (rc) return rc;
+  }
+  rc = sync_ctrs(c);
   if (rc) return rc;
   rc = sync_cb(c);
   if (rc) return rc;
@@ -1089,12 +1106,14 @@ static int bk_drain_to_table(kc_ctx *c) {
   HIPCHK(hipMemsetAsync(c->bb.used1, 0, (size_t)c->gm.G * 2 * 4, c->stream));
   HIPCHK(hipMemsetAsync(c->d_cb, 0, CB_COUNT * 8, c->stream));
   c->inc_on = false;  // (what instalments of level 2 had taken is still in the level-1 chains, which went to the table whole)
+  c->l2_per_bucket = 0;
   c->table_mode = true;
   return KC_OK;
 }
 
 static bool bk_active(const kc_ctx *c) { return c->tuning.mode != 1 && !c->table_mode; }
 static int bk_spill_pass(kc_ctx *c);
+static int bk_light_spill(kc_ctx *c, uint64_t buffered);
 static int bk_level2_instalment(kc_ctx *c);
 // A shard of several that has started the shard flow owns level-1 buckets, not hash values: the entry points that test
 // ownership per k-mer (kc_submit_*, kc_insert_records) would put records where its level 2 never looks.
@@ -1178,7 +1197,13 @@ static int run_extract_device(kc_ctx *c, const uint8_t *bases, const uint8_t *qu
       // 1 MB into its one table for as long as reads come, gpu_hash_table.cpp:681-695).  A block that is too large for
       // the whole buffer takes the table path as before.
       if (over_capacity && !c->sh.flow && c->expect_prev > c->expect_base && total - c->expect_prev <= c->bk_capacity) {
-        rc = bk_spill_pass(c);
+        // Compact records first try the light way: what level 1 holds goes through level 2 now (an instalment) and
+        // level 1 starts again empty -- its 8-byte records were the larger part of the buffer, the 4-byte records of level
+        // 2 stay until the regions are counted, once, at the end.  Nothing is counted twice, nothing merged: a buffer for
+        // 30 % of the input costs what one pass costs (scripts/spill_probe.py).  KC_ERR_OUT_OF_MEMORY: no room for level
+        // 2 to grow -- then, as for longer k-mers, the counted buffer is merged into the global table.
+        rc = bk_light_spill(c, c->expect_prev - c->expect_base);
+        if (rc == KC_ERR_OUT_OF_MEMORY || rc == KC_ERR_UNSUPPORTED_K) rc = bk_spill_pass(c);
         if (rc) return rc;
         c->expect_base = c->expect_prev;
         over_capacity = false;
@@ -1830,8 +1855,9 @@ extern "C" int kc_insert_records(kc_ctx *c, const uint64_t *d_records, uint64_t 
     if (rc) return rc;
     const uint64_t buffered = c->h_ctrs[CTR_EXPECT] - c->expect_base;
     bool fits = buffered + n <= c->bk_capacity;
-    if (!fits && buffered && n <= c->bk_capacity) {  // count what is buffered, merge it into the table, go on empty
-      rc = bk_spill_pass(c);
+    if (!fits && buffered && n <= c->bk_capacity) {  // hand what is buffered on to level 2 (compact records), or count it and merge it into the table; go on empty
+      rc = bk_light_spill(c, buffered);
+      if (rc == KC_ERR_OUT_OF_MEMORY || rc == KC_ERR_UNSUPPORTED_K) rc = bk_spill_pass(c);
       if (rc) return rc;
       c->expect_base = c->h_ctrs[CTR_EXPECT];
       fits = true;
@@ -2292,7 +2318,8 @@ static int bk_level2_launch(kc_ctx *c, bool inc) {
     fs.nbo = fs.b_hi - fs.b_lo;
   }
   if (!inc || !c->inc_on) {
-    const uint64_t per_bucket = inc ? (c->bk_capacity + c->gm.P1 - 1) / c->gm.P1 : 0;
+    if (inc && !c->l2_per_bucket) c->l2_per_bucket = (c->bk_capacity + c->gm.P1 - 1) / c->gm.P1;
+    const uint64_t per_bucket = inc ? c->l2_per_bucket : 0;
     hipLaunchKernelGGL(kc_bucket_prefix_kernel, dim3(1), dim3(WGB), 0, c->stream, c->gm, c->bb, fs, c->d_cb, per_bucket);
     c->num_gpu_calls++;
     if (inc) {
@@ -2323,6 +2350,121 @@ static int bk_level2_instalment(kc_ctx *c) {
     case 3: return bk_level2_launch<3>(c, true);
     default: return bk_level2_launch<4>(c, true);
   }
+}
+
+// Room in the level-2 arena for `need` compact records in all while level 2 runs in instalments: every bucket's part is
+// fixed up front (kc_bucket_prefix_kernel with per_bucket), so more records than planned mean a larger arena and, once
+// instalments have begun, the parts moved into it (kc_l2_grow_kernel).  KC_ERR_OUT_OF_MEMORY when the device has no room.
+static int bk_l2_reserve(kc_ctx *c, uint64_t need) {
+  const Geom &g = c->gm;
+  const uint64_t CH2 = 1ULL << g.log2CH2;
+  const uint64_t pb_need = (uint64_t)((double)need * 1.08 / (double)g.P1) + 2 * CH2;  // (buckets differ by a few per cent)
+  const uint64_t pb_now = c->inc_on ? c->l2_per_bucket : (c->bk_capacity + g.P1 - 1) / g.P1;
+  if (pb_need <= pb_now) {
+    if (!c->inc_on) c->l2_per_bucket = pb_now;
+    return KC_OK;
+  }
+  const uint64_t pb = c->inc_on ? std::max<uint64_t>(2 * pb_now, pb_need) : pb_need;
+  const uint64_t a2 = (uint64_t)g.P1 * ((pb + CH2 - 1) / CH2 + g.P2) + 16;
+  if (a2 >= (1ULL << 32)) return KC_ERR_OUT_OF_MEMORY;
+  uint64_t *bigger = nullptr;
+  const size_t bytes = (size_t)a2 * CH2 * 4;
+  size_t free_b = 0, total_b = 0;
+  if (hipMemGetInfo(&free_b, &total_b) != hipSuccess || free_b < bytes + ((size_t)4 << 30) || hipMalloc((void **)&bigger, bytes) != hipSuccess) {
+    (void)hipGetLastError();
+    return KC_ERR_OUT_OF_MEMORY;
+  }
+  if (c->inc_on) {
+    uint32_t *nb = nullptr;
+    if (hipMalloc((void **)&nb, ((size_t)g.P1 + 1) * 4) != hipSuccess) {
+      (void)hipGetLastError();
+      (void)hipFree(bigger);
+      return KC_ERR_OUT_OF_MEMORY;
+    }
+    BucketBufs tmp = c->bb;
+    tmp.base2 = nb;
+    FlatSrc fs;
+    memset(&fs, 0, sizeof(fs));
+    hipLaunchKernelGGL(kc_bucket_prefix_kernel, dim3(1), dim3(WGB), 0, c->stream, c->gm, tmp, fs, c->d_cb, pb);
+    hipLaunchKernelGGL(kc_l2_grow_kernel, dim3(g.P1), dim3(WGB), 0, c->stream, c->gm, reinterpret_cast<const uint32_t *>(c->bb.rec2),
+                       reinterpret_cast<uint32_t *>(bigger), c->bb.base2, nb, c->bb.used2, c->bb.chain2, c->bb.cnt2);
+    c->num_gpu_calls += 2;
+    hipError_t e = hipGetLastError();
+    if (e == hipSuccess) e = hipMemcpyAsync(c->bb.base2, nb, ((size_t)g.P1 + 1) * 4, hipMemcpyDeviceToDevice, c->stream);
+    if (e == hipSuccess) e = hipStreamSynchronize(c->stream);
+    (void)hipFree(nb);
+    if (e != hipSuccess) {
+      (void)hipFree(bigger);
+      return hip_fail(e, "bk_l2_reserve", __LINE__);
+    }
+  }
+  HIPCHK(hipFree(c->bb.rec2));
+  c->bk_bytes += bytes - c->bk_held[4];
+  c->bb.rec2 = bigger;
+  c->bk_held[4] = bytes;
+  c->gm.A2 = (uint32_t)a2;
+  c->l2_per_bucket = pb;
+  return KC_OK;
+}
+
+// The buffer is full and more reads are coming (compact records): level 1's records go through level 2 now, level 1
+// starts again empty, level 2 keeps what it has until the regions are counted.  buffered: records level 1 holds (an upper
+// bound).  KC_ERR_UNSUPPORTED_K: not a geometry this works for (the caller takes the other way).
+static int bk_light_spill(kc_ctx *c, uint64_t buffered) {
+  if (!c->gm.cp || c->nl != 1 || !bk_active(c) || !c->bk_ready || c->bk_level2 || c->sh.flow) return KC_ERR_UNSUPPORTED_K;
+  const char *e = getenv("KC_LIGHT_SPILL");
+  if (e && e[0] == '0') return KC_ERR_UNSUPPORTED_K;  // (A/B runs: the counted buffer merged into the global table, as for longer k-mers)
+  int rc = sync_cb(c);
+  if (rc) return rc;
+  if (c->h_cb[CB_FATAL]) {
+    snprintf(g_last_error, sizeof(g_last_error), "k-mer buffer: records were lost (fatal bits %llu)", (unsigned long long)c->h_cb[CB_FATAL]);
+    return KC_ERR_CAPACITY;
+  }
+  rc = bk_l2_reserve(c, c->l2_held + buffered);
+  if (rc) return rc;
+  // the region overflow list takes what this instalment's heavy regions spill: at least half of it free, or it grows
+  const uint64_t used2 = std::min<uint64_t>(c->h_cb[CB_OVF2], c->bb.ovf2_cap);
+  if (used2 * 2 > c->bb.ovf2_cap) {
+    const uint64_t cap = 2 * c->bb.ovf2_cap;
+    uint64_t *bigger = nullptr;
+    if (hipMalloc((void **)&bigger, cap * 8) != hipSuccess) {
+      (void)hipGetLastError();
+      return KC_ERR_OUT_OF_MEMORY;
+    }
+    HIPCHK(hipMemcpyAsync(bigger, c->bb.ovf2, used2 * 8, hipMemcpyDeviceToDevice, c->stream));
+    HIPCHK(hipStreamSynchronize(c->stream));
+    HIPCHK(hipFree(c->bb.ovf2));
+    c->bk_bytes += (cap - c->bb.ovf2_cap) * 8;
+    c->bb.ovf2 = bigger;
+    c->bb.ovf2_cap = cap;
+    c->bk_held[10] = cap * 8;
+  }
+  rc = bk_level2_launch<1>(c, true);
+  if (rc) return rc;
+  rc = sync_cb(c);
+  if (rc) return rc;
+  if (c->h_cb[CB_FATAL]) {
+    snprintf(g_last_error, sizeof(g_last_error),
+             "k-mer buffer: the region overflow list filled up in a pass over a buffer smaller than the input (fatal bits %llu): raise max_kmers_buffered",
+             (unsigned long long)c->h_cb[CB_FATAL]);
+    return KC_ERR_CAPACITY;
+  }
+  // what found no room at level 1 joins the flagged regions' list (as bk_level2_t does at the end of a pass)
+  const uint64_t n1 = std::min<uint64_t>(c->h_cb[CB_OVF1], c->bb.ovf1_cap);
+  if (n1) {
+    hipLaunchKernelGGL((kc_ovf1_to_regions_kernel<1, true>), dim3((unsigned)((n1 + 255) / 256)), dim3(256), 0, c->stream, c->gm, c->bb, n1, c->d_cb);
+    c->num_gpu_calls++;
+    HIPCHK(hipGetLastError());
+    HIPCHK(hipMemsetAsync(c->d_cb + CB_OVF1, 0, 8, c->stream));
+  }
+  // level 1 starts again: every chain empty, every writer's arena whole
+  HIPCHK(hipMemsetAsync(c->bb.cnt1, 0, (size_t)c->gm.G * c->gm.P1 * 4, c->stream));
+  HIPCHK(hipMemsetAsync(c->bb.done1, 0, (size_t)c->gm.G * c->gm.P1 * 4, c->stream));
+  HIPCHK(hipMemsetAsync(c->bb.used1, 0, (size_t)c->gm.G * 2 * 4, c->stream));
+  c->ovf1_ub = 0;
+  c->l2_held += buffered;
+  c->l1_dropped = true;
+  return KC_OK;
 }
 
 template <int NL>
@@ -2380,14 +2522,16 @@ static int bk_build_regions(kc_ctx *c) {
     if (rc) return rc;
     const uint64_t fatal = c->h_cb[CB_FATAL];
     if (!fatal) break;
-    if (fatal != FATAL_OVF2 || attempt > 0) {
-      snprintf(g_last_error, sizeof(g_last_error), "k-mer buffer: records were lost building the regions (fatal bits %llu)", (unsigned long long)fatal);
+    if (fatal != FATAL_OVF2 || attempt > 0 || c->l1_dropped) {  // (after a light spill level 1 no longer holds every record: no second run)
+      snprintf(g_last_error, sizeof(g_last_error), "k-mer buffer: records were lost building the regions (fatal bits %llu)%s", (unsigned long long)fatal,
+               c->l1_dropped ? ": the region overflow list filled up in a pass over a buffer smaller than the input -- raise max_kmers_buffered" : "");
       return KC_ERR_CAPACITY;
     }
     // The second overflow list was too small for the regions that outgrew their chains (heavy hitters).  Level 1 is
     // untouched and the counter kept counting past the end, so it says exactly how much room the same pass needs.
     // (After instalments the pass is run whole: the level-1 chains still hold every record.)
     c->inc_on = false;
+  c->l2_per_bucket = 0;
     const uint64_t need = c->h_cb[CB_OVF2] + c->h_cb[CB_OVF2] / 64 + 4096;
     uint64_t *bigger = nullptr;
     HIPCHK(hipMalloc((void **)&bigger, need * (size_t)c->nl * 8));
@@ -2749,6 +2893,9 @@ static int bk_spill_pass(kc_ctx *c) {
   HIPCHK(hipMemsetAsync(c->d_cb, 0, CB_COUNT * 8, c->stream));
   c->bk_level2 = c->bk_flagged = false;
   c->inc_on = false;
+  c->l2_per_bucket = 0;
+  c->l1_dropped = false;
+  c->l2_held = 0;
   c->bk_spilled = true;
   return KC_OK;
 }

@@ -1202,6 +1202,24 @@ __global__ __launch_bounds__(WGB) void kc_bucket_prefix_kernel(Geom gm, BucketBu
   }
 }
 
+// ---- the level-2 arena moves into a larger one (compact records; bk_l2_reserve) ---------------------------------------------
+// Every bucket's part of the arena grows: its used chunks are copied to where the part now starts, and the chunk ids of
+// its regions' chains move by the same amount.  One workgroup per bucket.
+__global__ __launch_bounds__(WGB) void kc_l2_grow_kernel(Geom gm, const uint32_t *old_rec, uint32_t *new_rec, const uint32_t *old_base,
+                                                        const uint32_t *new_base, const uint32_t *used2, uint32_t *chain2, const uint32_t *cnt2) {
+  const uint32_t b = blockIdx.x, tid = threadIdx.x;
+  const size_t words = (size_t)used2[b] << gm.log2CH2;  // 32-bit records
+  const uint32_t *src = old_rec + ((size_t)old_base[b] << gm.log2CH2);
+  uint32_t *dst = new_rec + ((size_t)new_base[b] << gm.log2CH2);
+  for (size_t i = tid; i < words; i += WGB) dst[i] = src[i];
+  const uint32_t delta = new_base[b] - old_base[b], CHm = (1u << gm.log2CH2) - 1u;
+  for (uint32_t r = tid; r < gm.P2; r += WGB) {
+    const size_t reg = (size_t)b * gm.P2 + r;
+    const uint32_t nch = min((cnt2[reg] + CHm) >> gm.log2CH2, gm.L2MAX);
+    for (uint32_t i = 0; i < nch; i++) chain2[reg * gm.L2MAX + i] += delta;
+  }
+}
+
 // ---- level 2 ------------------------------------------------------------------------------------------
 typedef uint64_t __attribute__((aligned(1))) U64Unaligned;  // an 8-byte load from any byte address (one instruction on gfx950)
 struct L2LDS {

@@ -445,6 +445,41 @@ def test_a_full_buffer_is_counted_and_merged_not_abandoned(k, tuning):
     assert "kc_extract_kernel<insert>" not in kt and kt["kc_l2_split_kernel"][0] >= 3
 
 
+@pytest.mark.parametrize("light", [True, False], ids=["light", "merged"])
+@pytest.mark.parametrize("path", ["compact", "compact-short"])
+@pytest.mark.parametrize("blocks_fit", [2.5, 1.2])
+def test_compact_records_leave_level_1_when_the_buffer_is_full(path, light, blocks_fit, monkeypatch):
+    """Compact records and a buffer smaller than the input: what level 1 holds goes through level 2 (an instalment) and
+    level 1 starts again empty -- level 2 keeps its 4-byte records until the regions are counted once, at the end, growing
+    its arena as the input grows (bk_light_spill, kc_l2_grow_kernel: with room for 1.2 blocks of eight the arena moves
+    several times).  Nothing is merged into the global table; KC_LIGHT_SPILL=0 takes the other way (the counted buffer
+    merged into the table, what longer k-mers do).  Bit-exact either way, the pre-purge dump too."""
+    if not light:
+        monkeypatch.setenv("KC_LIGHT_SPILL", "0")
+    k = 21
+    reads, quals = _reads_for_overflow(150, n=2400)
+    b, q, offs = arrays(reads, quals)
+    want, wtable, wst = oracle_run(b, q, offs, k)
+    per_block = sum(max(0, len(r) - k - 1) for r in reads[:300])
+    with pkg.KmerCounter(k, max_kmers_buffered=int(per_block * blocks_fit), tuning=PATHS[path], time_kernels=True) as kc:
+        for r0 in range(0, 2400, 300):
+            bb, qq, oo = arrays(reads[r0:r0 + 300], quals[r0:r0 + 300])
+            kc.submit_reads(bb, qq, oo)
+        gtable = kc.dump_table()
+        got = kc.sorted_results()
+        st = kc.stats()
+        kt = kc.kernel_times()
+    assert_same(got, want)
+    assert (gtable[0] == wtable[0]).all() and (gtable[1] == wtable[1]).all() and (gtable[2] == wtable[2]).all()
+    assert st["num_unique"] == wst["unique"] and st["num_purged"] == wst["purged"] and st["sum_counts"] == wst["sum_counts"]
+    assert st["kmers_inserted"] == wst["kmers_inserted"]
+    assert "kc_extract_kernel<insert>" not in kt and kt["kc_l2_split_kernel"][0] >= 3
+    # the light way merges no counted buffer into the global table (kc_merge_entries_kernel is timed as
+    # kc_insert_records_kernel; so is the one move of the overflow records at the end, which these reads provoke)
+    merges = kt.get("kc_insert_records_kernel", (0, 0.0))[0]
+    assert merges <= 1 if light else merges >= 2, kt
+
+
 def test_records_path_spills_a_full_buffer_too():
     k, R = 21, 2
     rng = np.random.default_rng(23)

@@ -943,8 +943,11 @@ __global__ __launch_bounds__(WGB) void kc_l1_reads16_kernel(ExtractArgs a, Geom 
     {
       // every k-mer of this super-tile has left it (the barrier after the histogram): stage the next one now
       const uint64_t nst = work ? st + gridDim.x : st;
-      tile_encode<FMT, TileSuper>(L.tile, raw, a, a.pos0 + (int64_t)nst * SUPER_SPAN, ctrs, tid, nst < nsuper);
-      tile_prefetch<FMT, TileSuper>(raw, a, a.pos0 + (int64_t)(nst + gridDim.x) * SUPER_SPAN, tid, next_first, nst + gridDim.x < nsuper);
+      // (the thread id as a fresh value: addresses that depend on it only are otherwise kept in registers across the whole
+      // loop, and in this kernel spilled)
+      const int ft = fresh_tid();
+      tile_encode<FMT, TileSuper>(L.tile, raw, a, a.pos0 + (int64_t)nst * SUPER_SPAN, ctrs, ft, nst < nsuper);
+      tile_prefetch<FMT, TileSuper>(raw, a, a.pos0 + (int64_t)(nst + gridDim.x) * SUPER_SPAN, ft, next_first, nst + gridDim.x < nsuper);
       next_first = first_of(nst + 2 * (uint64_t)gridDim.x);
       KC_SPLIT_STAMP(5)  // stage the next super-tile
     }
@@ -1256,6 +1259,7 @@ __global__ __launch_bounds__(WGB) void kc_l2_split_kernel(Geom gm, BucketBufs bb
   for (uint32_t b1 = (FL ? fs.b_lo : 0u) + blockIdx.x; b1 < (FL ? fs.b_hi : P1); b1 += gridDim.x) {
     // prefix over the segments of this bucket
     {
+      const int tid = fresh_tid();  // (hoisted out of the bucket loop, this address and the one of cnt2 below were spilled)
       uint32_t v = ((uint32_t)tid < G) ? bb.cnt1[(size_t)tid * P1 + b1] : 0u;
       if constexpr (INC) {
         const uint32_t d = ((uint32_t)tid < G) ? bb.done1[(size_t)tid * P1 + b1] : 0u;
@@ -1411,10 +1415,13 @@ __global__ __launch_bounds__(WGB) void kc_l2_split_kernel(Geom gm, BucketBufs bb
           });
       buf ^= 1;
     }
-    if ((uint32_t)tid < P2) bb.cnt2[(size_t)b1 * P2 + tid] = cst.cur;
-    if constexpr (INC) {
-      if ((uint32_t)tid < G) bb.done1[(size_t)tid * P1 + b1] = L.skip[tid] + (L.pre[tid + 1] - L.pre[tid]);
-      if (tid == 0) bb.used2[b1] = min(L.sp.arena_used, D.arena_cap);
+    {
+      const int tid = fresh_tid();
+      if ((uint32_t)tid < P2) bb.cnt2[(size_t)b1 * P2 + tid] = cst.cur;
+      if constexpr (INC) {
+        if ((uint32_t)tid < G) bb.done1[(size_t)tid * P1 + b1] = L.skip[tid] + (L.pre[tid + 1] - L.pre[tid]);
+        if (tid == 0) bb.used2[b1] = min(L.sp.arena_used, D.arena_cap);
+      }
     }
     __syncthreads();
   }

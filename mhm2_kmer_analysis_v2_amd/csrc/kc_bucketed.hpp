@@ -740,8 +740,10 @@ constexpr size_t l1x16_lds_bytes() { return ((sizeof(L1LDS) + 15) & ~size_t(15))
 // scan (of the run lengths rounded up to even), reserve, scatter.  br[j] = bucket | extension codes << 10 | rank << 16,
 // or ~0.  dst[b] = {x, y as in split_stage, start | run length << 16, records that found room | of which in the old
 // last chunk << 16}.  Returns the staged total (pads included).
+// mid(): what the kernel has to do between the scatter and the barrier behind it (the next super-tile's staging)
+template <class MidFn>
 __device__ __forceinline__ uint32_t split_stage_pairs(SplitLDS &L, uint32_t *slo, uint16_t *sbk, int buf, uint32_t P, const uint32_t (&lo)[R16],
-                                                      const uint32_t (&br)[R16], const ChainDest &D, ChainState &st) {
+                                                      const uint32_t (&br)[R16], const ChainDest &D, ChainState &st, MidFn mid) {
   const int tid = fresh_tid();
   KC_SPLIT_STAMP(1)  // barrier after the histogram
   const uint32_t v = ((uint32_t)tid < P) ? L.hist[buf][tid] : 0u;
@@ -807,8 +809,9 @@ __device__ __forceinline__ uint32_t split_stage_pairs(SplitLDS &L, uint32_t *slo
       sbk[p] = (uint16_t)bj;
     }
   }
+  mid();
   lds_barrier();
-  KC_SPLIT_STAMP(3)  // scatter to LDS
+  KC_SPLIT_STAMP(3)  // scatter to LDS (+ the next super-tile's staging)
   return total;
 }
 
@@ -903,61 +906,60 @@ __global__ __launch_bounds__(WGB) void kc_l1_reads16_kernel(ExtractArgs a, Geom 
   tile_prefetch<FMT, TileSuper>(raw, a, a.pos0 + (int64_t)blockIdx.x * SUPER_SPAN, tid, first_of(blockIdx.x), blockIdx.x < nsuper);
   uint64_t next_first = first_of((uint64_t)blockIdx.x + gridDim.x);
   constexpr int RUNS = SUPER_SPAN / R16;
-  // iteration -1 only stages the first super-tile; every further one is staged between its predecessor's scatter and
-  // copy-out (one place in the code for the staging)
-  for (int64_t it = -1;; it++) {
-    const uint64_t st = (uint64_t)blockIdx.x + (uint64_t)(it < 0 ? 0 : it) * gridDim.x;
-    const bool work = it >= 0;  // the same for every thread of the workgroup
-    if (work && st >= nsuper) break;
-    uint32_t total = 0;
-    if (work) {
-      uint32_t lo[R16], br[R16];
-      const bool active = tid < RUNS;
-      const int lp0 = PRE + (active ? tid : 0) * R16;
-      {
-        uint32_t l8[8], b8[8];
-        cp_run_fixed<KK, 8, SH>(L.tile, lp0, active, gm, a, l8, b8);
-#pragma unroll
-        for (int j = 0; j < 8; j++) {
-          lo[j] = l8[j];
-          br[j] = b8[j];
-        }
-        cp_run_fixed<KK, 8, SH>(L.tile, lp0 + 8, active, gm, a, l8, b8);
-#pragma unroll
-        for (int j = 0; j < 8; j++) {
-          lo[8 + j] = l8[j];
-          br[8 + j] = b8[j];
-        }
-      }
-#pragma unroll
-      for (int j = 0; j < R16; j++) {
-        const bool valid = br[j] != ~0u;
-        const uint32_t rank = hist_rank(L.sp, buf, br[j] & (PMAX - 1), valid);
-        br[j] = valid ? (br[j] | (rank << 16)) : ~0u;
-        n_ins += valid ? 1u : 0u;
-      }
-      KC_SPLIT_STAMP(0)  // cut the k-mers out of the super-tile, histogram
-      lds_barrier();
-      total = split_stage_pairs(L.sp, slo, sbk, buf, P1, lo, br, D, cst);
-    }
+  // The first super-tile is staged up front.  Every further one is staged INSIDE its predecessor's round, between barriers
+  // the round has anyway: its gap words are cleared after the barrier behind the histogram (every k-mer has left the old
+  // tile by then), its codes are written beside the scatter, and the barrier behind the scatter completes it -- the two
+  // barriers of a staging by itself, and the skew the waves collect in front of them, are gone.
+  {
+    const int ft = fresh_tid();
+    tile_encode<FMT, TileSuper>(L.tile, raw, a, a.pos0 + (int64_t)blockIdx.x * SUPER_SPAN, ctrs, ft, blockIdx.x < nsuper);
+    tile_prefetch<FMT, TileSuper>(raw, a, a.pos0 + (int64_t)((uint64_t)blockIdx.x + gridDim.x) * SUPER_SPAN, ft, next_first,
+                                  (uint64_t)blockIdx.x + gridDim.x < nsuper);
+    next_first = first_of((uint64_t)blockIdx.x + 2 * (uint64_t)gridDim.x);
+  }
+  for (uint64_t st = blockIdx.x; st < nsuper; st += gridDim.x) {
+    uint32_t lo[R16], br[R16];
+    const bool active = tid < RUNS;
+    const int lp0 = PRE + (active ? tid : 0) * R16;
     {
-      // every k-mer of this super-tile has left it (the barrier after the histogram): stage the next one now
-      const uint64_t nst = work ? st + gridDim.x : st;
-      // (the thread id as a fresh value: addresses that depend on it only are otherwise kept in registers across the whole
-      // loop, and in this kernel spilled)
-      const int ft = fresh_tid();
-      tile_encode<FMT, TileSuper>(L.tile, raw, a, a.pos0 + (int64_t)nst * SUPER_SPAN, ctrs, ft, nst < nsuper);
+      uint32_t l8[8], b8[8];
+      cp_run_fixed<KK, 8, SH>(L.tile, lp0, active, gm, a, l8, b8);
+#pragma unroll
+      for (int j = 0; j < 8; j++) {
+        lo[j] = l8[j];
+        br[j] = b8[j];
+      }
+      cp_run_fixed<KK, 8, SH>(L.tile, lp0 + 8, active, gm, a, l8, b8);
+#pragma unroll
+      for (int j = 0; j < 8; j++) {
+        lo[8 + j] = l8[j];
+        br[8 + j] = b8[j];
+      }
+    }
+#pragma unroll
+    for (int j = 0; j < R16; j++) {
+      const bool valid = br[j] != ~0u;
+      const uint32_t rank = hist_rank(L.sp, buf, br[j] & (PMAX - 1), valid);
+      br[j] = valid ? (br[j] | (rank << 16)) : ~0u;
+      n_ins += valid ? 1u : 0u;
+    }
+    KC_SPLIT_STAMP(0)  // cut the k-mers out of the super-tile, histogram
+    lds_barrier();
+    // (the thread id as a fresh value: addresses that depend on it only are otherwise kept in registers across the whole
+    // loop, and in this kernel spilled)
+    const int ft = fresh_tid();
+    const uint64_t nst = st + gridDim.x;
+    tile_encode_clear<TileSuper>(L.tile, raw, ft);
+    const uint32_t total = split_stage_pairs(L.sp, slo, sbk, buf, P1, lo, br, D, cst, [&]() {
+      tile_encode_fill<FMT, TileSuper>(L.tile, raw, a, a.pos0 + (int64_t)nst * SUPER_SPAN, ctrs, ft, nst < nsuper);
       tile_prefetch<FMT, TileSuper>(raw, a, a.pos0 + (int64_t)(nst + gridDim.x) * SUPER_SPAN, ft, next_first, nst + gridDim.x < nsuper);
       next_first = first_of(nst + 2 * (uint64_t)gridDim.x);
-      KC_SPLIT_STAMP(5)  // stage the next super-tile
-    }
-    if (work) {
-      split_copy_out_pairs(L.sp, slo, sbk, total, D, gm, [&](uint64_t r) {
-        const uint64_t rr[1] = {r};
-        l1_overflow<1, true>(gm, bb, cb, rr);
-      });
-      buf ^= 1;
-    }
+    });
+    split_copy_out_pairs(L.sp, slo, sbk, total, D, gm, [&](uint64_t r) {
+      const uint64_t rr[1] = {r};
+      l1_overflow<1, true>(gm, bb, cb, rr);
+    });
+    buf ^= 1;
   }
   if ((uint32_t)tid < P1) bb.cnt1[(size_t)g * P1 + tid] = cst.cur;
   if (tid == 0) {

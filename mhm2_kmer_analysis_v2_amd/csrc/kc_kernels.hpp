@@ -320,10 +320,30 @@ __device__ __forceinline__ void tile_prefetch(TileRaw<G> &R, const ExtractArgs &
   if (FMT != FMT_SEQBLOCK && active && tile_first_read + tid <= a.nreads) R.off = a.offsets[tile_first_read + tid];
 }
 
+// tile_encode in two halves for a kernel that has barriers of its own to put between and behind them (kc_l1_reads16_kernel):
+// tile_encode_clear, BARRIER, tile_encode_fill, BARRIER.
+template <class G>
+__device__ __forceinline__ void tile_encode_clear(TileLDS<G> &L, const TileRaw<G> &R, int tid) {
+  for (int i = tid; i < G::NWORD + 1; i += G::THREADS) L.gap[i] = 0;
+  if (tid == G::THREADS - 1) L.far_off = R.off;
+}
+template <int FMT, class G>
+__device__ __forceinline__ void tile_encode_fill(TileLDS<G> &L, const TileRaw<G> &R, const ExtractArgs &a, int64_t T0, uint64_t *ctrs, int tid,
+                                                 bool active);
+
 template <int FMT, class G>
 __device__ __forceinline__ void tile_encode(TileLDS<G> &L, const TileRaw<G> &R, const ExtractArgs &a, int64_t T0, uint64_t *ctrs, int tid,
                                             bool active) {
   // every thread of the workgroup reaches both barriers
+  tile_encode_clear<G>(L, R, tid);
+  tile_barrier();
+  tile_encode_fill<FMT, G>(L, R, a, T0, ctrs, tid, active);
+  tile_barrier();
+}
+
+template <int FMT, class G>
+__device__ __forceinline__ void tile_encode_fill(TileLDS<G> &L, const TileRaw<G> &R, const ExtractArgs &a, int64_t T0, uint64_t *ctrs, int tid,
+                                                 bool active) {
 #ifdef KC_STAMPS
   unsigned long long ts_ = __builtin_amdgcn_s_memtime();
 #define KC_ENC_STAMP(k)                                                              \
@@ -335,14 +355,8 @@ __device__ __forceinline__ void tile_encode(TileLDS<G> &L, const TileRaw<G> &R, 
 #else
 #define KC_ENC_STAMP(k)
 #endif
-  for (int i = tid; i < G::NWORD + 1; i += G::THREADS) L.gap[i] = 0;
-  if (tid == G::THREADS - 1) L.far_off = R.off;
-  tile_barrier();
   KC_ENC_STAMP(0)
-  if (!active) {
-    tile_barrier();
-    return;
-  }
+  if (!active) return;
   const int64_t lo = a.align, hi = (int64_t)a.align + (int64_t)a.total;
   bool bad = false;
 #pragma unroll
@@ -437,8 +451,6 @@ __device__ __forceinline__ void tile_encode(TileLDS<G> &L, const TileRaw<G> &R, 
   }
   if (bad) ctrs[CTR_BAD_BASE] = 1;
   KC_ENC_STAMP(2)
-  tile_barrier();
-  KC_ENC_STAMP(3)
 }
 
 // both halves back to back (kernels that do not pipeline their tiles)

@@ -824,7 +824,10 @@ template <class OvfFn>
 __device__ __forceinline__ void split_copy_out_pairs(SplitLDS &L, const uint32_t *slo, const uint16_t *sbk, uint32_t total, const ChainDest &D,
                                                      const Geom &gm, OvfFn overflow) {
   const int tid = fresh_tid();
-  constexpr int U = 4;  // pairs per thread and trip: first all their records, then all their destinations, then the stores
+#ifndef KC_COPY_U
+#define KC_COPY_U 2
+#endif
+  constexpr int U = KC_COPY_U;  // pairs per thread and trip: first all their records, then all their destinations, then the stores
   uint64_t *const arena0 = D.arena + ((size_t)D.arena_base << D.log2CH);
   const uint32_t shb = 32u - gm.la, shl = 64u - gm.k2;  // the bucket in the high word; the 32 bits below it start here (shl < 32)
   for (uint32_t i0 = 2u * (uint32_t)tid; i0 < total; i0 += 2u * U * WGB) {

@@ -1672,6 +1672,70 @@ __device__ __forceinline__ uint32_t lds_probe32(uint32_t *claim, uint32_t Sm1, u
 #endif
 }
 
+template <int NL>
+__device__ __forceinline__ uint32_t lds_probeN(const CountTab &tb, const uint64_t (&key)[NL], uint32_t slot, uint32_t valid, uint32_t &failed);
+
+// Two-word keys, the probe written out like lds_probe32: the execution mask is the set of lanes still probing.  A trip:
+// the compare-and-swap of the claim word (EMPTY -> BUSY) and, right behind it, the read of the other word (the LDS serves a
+// wave's requests in order: a lane that finds the key's last word published reads a first word written before the
+// publication); one wait; the winners write their first word and publish; "same" = both words equal; a lane that found
+// BUSY looks at the same slot again; everybody else moves on by one slot.  24 instructions a trip against the 60-odd the
+// compiler makes of lds_probeN<2> (exec saved and restored around every conditional LDS access, every predicate through
+// a vector register).  Returns the slot; failed |= 1 when every slot holds some other k-mer.
+__device__ __forceinline__ uint32_t lds_probe2(const CountTab &tb, uint64_t key0, uint64_t klast, uint32_t slot, bool valid, uint32_t &failed) {
+#ifndef KC_PROBE2_CXX
+  const uint32_t m8 = (tb.S - 1u) << 3;
+  uint32_t at = slot << 3, a0, a1, trips = 4u * tb.S + 2u;
+  const uint32_t base0 = (uint32_t)(uintptr_t)tb.keys, base1 = base0 + (tb.S << 3);  // word 0 of every slot, then the claim words
+  const uint64_t live = __builtin_amdgcn_ballot_w64(valid);
+  const uint64_t empty = KEY_EMPTY, busy = KEY_BUSY;
+  uint64_t old, w0, sv, act, won, t1, t2;
+  asm volatile(
+      "s_mov_b64 %[sv], exec\n\t"
+      "s_and_b64 %[act], exec, %[live]\n\t"
+      "s_mov_b64 exec, %[act]\n\t"
+      "s_cbranch_execz 2f\n"
+      "1:\n\t"
+      "v_add_u32_e32 %[a1], %[base1], %[at]\n\t"
+      "v_add_u32_e32 %[a0], %[base0], %[at]\n\t"
+      "ds_cmpst_rtn_b64 %[old], %[a1], %[empty], %[busy]\n\t"
+      "ds_read_b64 %[w0], %[a0]\n\t"
+      "s_waitcnt lgkmcnt(0)\n\t"
+      "v_cmp_eq_u64_e64 %[won], %[old], %[empty]\n\t"
+      "s_and_b64 exec, %[act], %[won]\n\t"          // the lanes that claimed a slot: first word, then the publication
+      "ds_write_b64 %[a0], %[key0]\n\t"
+      "ds_write_b64 %[a1], %[klast]\n\t"
+      "s_mov_b64 exec, %[act]\n\t"
+      "v_cmp_eq_u64_e64 %[t1], %[old], %[klast]\n\t"
+      "v_cmp_eq_u64_e64 %[t2], %[w0], %[key0]\n\t"
+      "s_and_b64 %[t1], %[t1], %[t2]\n\t"            // the slot holds this key
+      "s_or_b64 %[t1], %[t1], %[won]\n\t"
+      "s_andn2_b64 %[act], %[act], %[t1]\n\t"        // the lanes that go on
+      "s_mov_b64 exec, %[act]\n\t"
+      "s_cbranch_execz 2f\n\t"
+      "v_cmp_ne_u64_e64 %[t2], %[old], %[busy]\n\t"  // (a slot being written: look again; any other: next slot)
+      "s_and_b64 exec, %[act], %[t2]\n\t"
+      "v_add_u32_e32 %[at], 8, %[at]\n\t"
+      "v_and_b32_e32 %[at], %[m8], %[at]\n\t"
+      "s_mov_b64 exec, %[act]\n\t"
+      "s_sub_u32 %[trips], %[trips], 1\n\t"
+      "s_cmp_lg_u32 %[trips], 0\n\t"
+      "s_cbranch_scc1 1b\n\t"
+      "v_mov_b32_e32 %[fl], 1\n"                      // every slot holds some other k-mer
+      "2:\n\t"
+      "s_mov_b64 exec, %[sv]\n\t"
+      : [old] "=&v"(old), [w0] "=&v"(w0), [a0] "=&v"(a0), [a1] "=&v"(a1), [at] "+v"(at), [fl] "+v"(failed), [trips] "+s"(trips), [sv] "=&s"(sv),
+        [act] "=&s"(act), [won] "=&s"(won), [t1] "=&s"(t1), [t2] "=&s"(t2)
+      : [live] "s"(live), [base0] "s"(base0), [base1] "s"(base1), [empty] "v"(empty), [busy] "v"(busy), [key0] "v"(key0), [klast] "v"(klast),
+        [m8] "s"(m8)
+      : "vcc", "scc", "memory");
+  return at >> 3;
+#else
+  const uint64_t key[2] = {key0, klast};
+  return lds_probeN<2>(tb, key, slot, valid ? 1u : 0u, failed);
+#endif
+}
+
 // Several-word keys, same style: the last word is the claim word (EMPTY -> BUSY -> the key's last word), the others
 // are written between the claim and its publication.  A lane that finds BUSY tries the same slot again (its owner
 // publishes within this same trip of its own wave); a lane that finds its last word compares the other words.
@@ -1933,7 +1997,9 @@ __global__ __launch_bounds__(WGB, 8) void kc_count_kernel(Geom gm, BucketBufs bb
             for (int w = 0; w < NL; w++) key[w] = rec[j][w];
             const uint32_t le = (uint32_t)(rec[j][NL - 1] & 7u), re = (uint32_t)((rec[j][NL - 1] >> 3) & 7u);
             key[NL - 1] &= ~KC_EXT_MASK;
-            const uint32_t s = lds_probeN<NL>(tb, key, hash_slot(kc_hash<NL>(key), S), v, failed);
+            uint32_t s;
+            if constexpr (NL == 2) s = lds_probe2(tb, key[0], key[1], hash_slot(kc_hash<NL>(key), S), v != 0u, failed);
+            else s = lds_probeN<NL>(tb, key, hash_slot(kc_hash<NL>(key), S), v, failed);
             if (v && !(failed & 1u)) ext_count<EW>(tb, s, le, re);
           }
           if (failed) T.fail[buf] = 1;

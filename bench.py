@@ -22,7 +22,7 @@ sys.path.insert(0, ROOT)
 
 ALG_BYTES_PER_KMER = {1: 34.0, 2: 46.0, 3: 58.0, 4: 70.0}  # SURVEY.md section 8d contract constants, by num_longs
 HBM_PEAK_GBPS = 8000.0  # MI355X_MICROARCH.md: 8.0 TB/s spec
-PROFILE = "profiles/r03_pmc_50Mreads.json"  # rocprofv3 PMC passes of this same command (scripts/pmc_profile.sh)
+PROFILE = "profiles/r04_pmc_50Mreads.json"  # rocprofv3 PMC passes of this same command (scripts/pmc_profile.sh)
 
 
 def own_alg_bytes(kernel, nl, k, read_len, results_per_raw):

@@ -126,7 +126,7 @@ KC_HD uint64_t kc_hash(const uint64_t (&key)[NL]) {
   return ((uint64_t)(a2 ^ b2) << 32) | (uint64_t)(a ^ b);
 }
 
-// ---- an invertible mix of a short k-mer (k <= 23): four Feistel rounds on its two k-bit halves -------------------
+// ---- an invertible mix of a short k-mer (k <= 23): three Feistel rounds on its two k-bit halves -------------------
 // The bucketed path of one-word k-mers splits and probes on the bits of this value instead of a hash of the k-mer:
 // because the map is a bijection, the bits that name a record's bucket and region need not be stored with it, which
 // halves the records of the second level, and the k-mer is recovered from (region, remaining bits) when the results

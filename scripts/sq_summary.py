@@ -16,6 +16,8 @@ for f in sys.argv[1:]:
 wave_records = 6.5e9 / 64
 for k in HOT:
     v = agg[k]
+    if not any(kk == k for (kk, f) in ndisp):
+        continue
     nd = max(len(s) for (kk, f), s in ndisp.items() if kk == k)
     steps = nd / (5 if "l1_reads" in k else 1)   # the stage step and the end-to-end legs run the same kernels
     print("%s: %d dispatches = %.0f passes over 50 M reads" % (k, nd, steps))

@@ -223,7 +223,10 @@ int kc_insert_records(kc_ctx *ctx, const uint64_t *d_records, uint64_t n);
 /* Sender: count_kmers' loop body for one block of reads (src/kcount/kcount.cpp:71-90) + add_supermer for all of it.
  * d_segments: device buffer of rank_n * seg_words u64; segment d (at d * seg_words) receives what shard d owns,
  * h_words[d] = how many words of it to ship (0 for rank_me and for an empty block).  A block of R reads of length L
- * needs about R * (L - k - 1) / rank_n * kc_record_longs(k) * 1.1 + 1024 words per segment.  KC_ERR_CAPACITY when a segment is
+ * needs about R * (L - k - 1) / rank_n * kc_record_longs(k) * 1.1 + 1024 words per segment at most -- the compact records
+ * of k <= 21 with 1024 level-1 buckets travel as FIVE BYTES each (the segment is sorted by bucket, which is therefore
+ * implied: the reference compresses its wire too, as supermers, kmer_dht.cpp:69-100), 5/8 of that; h_words says what the
+ * segment really holds.  A segment is opaque to the caller: ship h_words[d] words as they are.  KC_ERR_CAPACITY when a segment is
  * too small (the block's k-mers then stay buffered in this context; nothing was shipped) or when the context would
  * hold more than max_kmers_buffered. */
 int kc_shard_extract(kc_ctx *ctx, const uint8_t *bases, const uint8_t *quals, const uint64_t *offsets, uint64_t nreads, int on_device,

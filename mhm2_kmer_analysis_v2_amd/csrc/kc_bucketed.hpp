@@ -2031,27 +2031,46 @@ __global__ __launch_bounds__(WGB, 8) void kc_count_kernel(Geom gm, BucketBufs bb
       // of the table (the vote and the write were 6 of the kernel's 23 ms); the list keeps the vote to the first few
       // waves.  The survivors of a wave take their ranks from ONE add to the region's counter and are written straight
       // to their places; every visited slot is left clean.
-      for (uint32_t s0 = 0; s0 < S; s0 += WGB) {
-        const uint32_t s = s0 + tid;
-        bool taken = false;
-        if (s < S) taken = CP ? keys32[s] != 0xFFFFFFFFu : tb.keys[(NL - 1) * SM + s] != KEY_EMPTY;
-        bool cand = false;
-        if (taken && !failed && !KC_ABL(gm, 3)) {
-          const uint32_t w0 = tb.ext[s], w1 = tb.ext[SM + s], w2 = tb.ext[(EW == 5 ? 4 : 2) * SM + s];
-          // the k-mer's count: every occurrence bumped exactly one of the left side's counters (<= 65535: n is)
-          const uint32_t count = (w0 & 0xFFFFu) + (w0 >> 16) + (w1 & 0xFFFFu) + (w1 >> 16) + (w2 & 0xFFFFu);
-          cand = DUMP || count >= 2;
-          acc_entries++;
+      // (two slots per thread and trip, every LDS read of both requested before the first is used and no branch around
+      // them -- an empty slot's counters are zero anyway --, one bump of the list's counter per wave and trip: the pass is a
+      // chain of LDS round trips, KC_STAMPS puts it at 37 % of the kernel's time for a dozen instructions a slot)
+      for (uint32_t s0 = 0; s0 < S; s0 += 2 * WGB) {
+        uint32_t sx[2];
+        bool in[2], taken[2], cand[2];
+        uint32_t w[2][3];
+#pragma unroll
+        for (int u = 0; u < 2; u++) {
+          sx[u] = s0 + (uint32_t)u * WGB + tid;
+          in[u] = sx[u] < S;
+          const uint32_t si = in[u] ? sx[u] : 0u;
+          taken[u] = in[u] && (CP ? keys32[si] != 0xFFFFFFFFu : tb.keys[(NL - 1) * SM + si] != KEY_EMPTY);
+          w[u][0] = tb.ext[si];
+          w[u][1] = tb.ext[SM + si];
+          w[u][2] = tb.ext[(EW == 5 ? 4 : 2) * SM + si];
         }
-        const uint64_t m = __ballot(cand);
-        if (m) {  // wave-uniform
-          const int leader = __ffsll((long long)m) - 1;
+#pragma unroll
+        for (int u = 0; u < 2; u++) {
+          cand[u] = false;
+          if (taken[u] && !failed && !KC_ABL(gm, 3)) {
+            // the k-mer's count: every occurrence bumped exactly one of the left side's counters (<= 65535: n is)
+            const uint32_t count = (w[u][0] & 0xFFFFu) + (w[u][0] >> 16) + (w[u][1] & 0xFFFFu) + (w[u][1] >> 16) + (w[u][2] & 0xFFFFu);
+            cand[u] = DUMP || count >= 2;
+            acc_entries++;
+          }
+        }
+        const uint64_t m0 = __ballot(cand[0]), m1 = __ballot(cand[1]);
+        if (m0 | m1) {  // wave-uniform
+          const uint32_t n0 = (uint32_t)__popcll(m0);
           uint32_t base = 0;
-          if ((int)lane_id() == leader) base = atomicAdd(&T.ncand, (uint32_t)__popcll(m));
-          base = __shfl(base, leader);
-          if (cand) tb.cand[base + (uint32_t)__popcll(m & ((1ULL << lane_id()) - 1ULL))] = (uint16_t)s;
+          if (lane_id() == 0) base = atomicAdd(&T.ncand, n0 + (uint32_t)__popcll(m1));
+          base = __shfl(base, 0);
+          const uint64_t below = (1ULL << lane_id()) - 1ULL;
+          if (cand[0]) tb.cand[base + (uint32_t)__popcll(m0 & below)] = (uint16_t)sx[0];
+          if (cand[1]) tb.cand[base + n0 + (uint32_t)__popcll(m1 & below)] = (uint16_t)sx[1];
         }
-        if (taken && !cand) reset_slot(s);  // leave the table clean for the next region
+#pragma unroll
+        for (int u = 0; u < 2; u++)
+          if (taken[u] && !cand[u]) reset_slot(sx[u]);  // leave the table clean for the next region
       }
       __syncthreads();
       const uint32_t ncand = T.ncand;

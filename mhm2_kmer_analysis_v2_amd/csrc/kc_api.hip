@@ -1049,10 +1049,21 @@ static int launch_l1_records_t(kc_ctx *c, const uint64_t *recs, uint64_t n) {
   auto kern = use_cp<NL>(c) ? kc_l1_records_kernel<NL, NL == 1> : kc_l1_records_kernel<NL, false>;
   c->gm.own_lo = 0;
   c->gm.own_hi = PMAX;
-  int rc = set_dyn_lds(kern, lds_l1_records<NL>());
-  if (rc) return rc;
   const uint64_t per_round = (uint64_t)WGB * Rnd<NL>::RPOS;
   const unsigned grid = (unsigned)std::min<uint64_t>(c->gm.G, (n + per_round - 1) / per_round);
+  if constexpr (NL == 1) {
+    static_assert(Rnd<1>::RPOS == R16, "both kernels take sixteen records per thread and round");
+    if (use_cp<NL>(c) && c->gm.k2 - c->gm.la <= 32) {  // short form: 6-byte staging, pair stores (kc_l1_records16_kernel)
+      int rc16 = set_dyn_lds(kc_l1_records16_kernel, l1r16_lds_bytes());
+      if (rc16) return rc16;
+      KernelTimer kt(c, KT_L1_RECORDS);
+      hipLaunchKernelGGL(kc_l1_records16_kernel, dim3(grid), dim3(WGB), l1r16_lds_bytes(), c->stream, recs, n, c->gm, c->bb, c->bk_rot, c->d_ctrs, c->d_cb);
+      c->bk_rot = (uint32_t)((c->bk_rot + (n + per_round - 1) / per_round) % c->gm.G);
+      return KC_OK;
+    }
+  }
+  int rc = set_dyn_lds(kern, lds_l1_records<NL>());
+  if (rc) return rc;
   KernelTimer kt(c, KT_L1_RECORDS);
   hipLaunchKernelGGL(kern, dim3(grid), dim3(WGB), lds_l1_records<NL>(), c->stream, recs, n, c->gm, c->bb, c->bk_rot, c->d_ctrs, c->d_cb);
   c->bk_rot = (uint32_t)((c->bk_rot + (n + per_round - 1) / per_round) % c->gm.G);

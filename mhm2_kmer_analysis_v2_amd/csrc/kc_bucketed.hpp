@@ -592,6 +592,44 @@ __device__ __forceinline__ void cp_run_fixed(const TL &L, int lp0, bool active, 
   }
 }
 
+// The same cut for a consumer that wants the k-mer records themselves (the sender side of the records flow): rec[j] = the
+// canonical k-mer, first base highest, with the extension codes in its low six bits (KC_EXT_MASK), h[j] = kc_hash of the
+// bare k-mer, ok bit j = the window of k-mer j lies inside one read.
+template <int K, int RPOS, class TL>
+__device__ __forceinline__ uint32_t cut_run_fixed(const TL &L, int lp0, bool active, uint64_t (&rec)[RPOS], uint64_t (&h)[RPOS]) {
+  constexpr int NB = RPOS + K + 1;
+  static_assert(NB <= 32 && RPOS % 8 == 0 && PRE % 8 == 0, "the window must fit one word and never start word-aligned");
+  const uint64_t *W = reinterpret_cast<const uint64_t *>(L.codes);
+  const uint32_t *OK = reinterpret_cast<const uint32_t *>(L.ok);
+  const int p = lp0 - 1, q = p >> 5, s = p & 31;
+  const uint64_t w0 = W[q], w1 = W[q + 1];
+  const uint32_t ok0 = OK[q], ok1 = OK[q + 1], g0 = L.gap[q], g1 = L.gap[q + 1];
+  const uint64_t Wn = (w0 << (2 * s)) | (w1 >> (64 - 2 * s));
+  const uint32_t nok = ~__builtin_amdgcn_alignbit(ok1, ok0, (uint32_t)s);
+  const uint32_t gapw = __builtin_amdgcn_alignbit(g1, g0, (uint32_t)s);
+  const uint64_t Rn = kc_rc_word(Wn) << (64 - 2 * NB);
+  constexpr uint64_t MID = ((1ULL << (2 * K)) - 1ULL) << 2;
+  constexpr uint64_t CMP = (K & 1) ? (MID | 3ULL) : MID;
+  uint32_t okm = 0;
+#pragma unroll
+  for (int j = 0; j < RPOS; j++) {
+    const uint64_t x = Wn >> (64 - 2 * (j + K + 2)), y = Rn >> (64 - 2 * (RPOS - 1 - j + K + 2));
+    const bool swap = (y & CMP) < (x & CMP);
+    const uint64_t sel = swap ? y : x;
+    const uint32_t na = (nok >> j) & 1u, nb = (nok >> (j + K + 1)) & 1u;
+    const uint32_t le = ((uint32_t)(sel >> (2 * K + 2)) & 3u) | ((swap ? nb : na) << 2);
+    const uint32_t re = ((uint32_t)sel & 3u) | ((swap ? na : nb) << 2);
+    const uint64_t key = (sel >> 2) << (64 - 2 * K);  // (the left neighbour above the k-mer leaves at the top)
+    const uint64_t kk[1] = {key};
+    h[j] = kc_hash<1>(kk);
+    // (a code >= 4 means "none": the records that travel carry exactly 4 then, like the general cut's)
+    rec[j] = key | (uint64_t)((le & 4u) ? 4u : le) | ((uint64_t)((re & 4u) ? 4u : re) << 3);
+    const bool valid = active && ((gapw >> (j + 1)) & ((1u << (K + 1)) - 1u)) == 0u;
+    okm |= valid ? (1u << j) : 0u;
+  }
+  return okm;
+}
+
 // SH: the context is one shard of several and keeps only the k-mers it owns (kc_submit_reads with rank_n > 1); the
 // single-shard instantiation carries none of the ownership code.
 // KK: k when the instantiation is made for one k (compact records only: cp_run_fixed), 0 = any k
@@ -1045,14 +1083,28 @@ __global__ __launch_bounds__(WGB) void kc_bin_reads_kernel(ExtractArgs a, uint64
       const int run_id = round * WGB + tid;
       const bool active = run_id < RUNS;
       const int lp0 = PRE + (active ? run_id : 0) * RPOS;
+      // k = 21 (MHM2's one-word k) with the library's own partition: the run cut out of one window by constant shifts
+      bool fixed21 = false;
+      uint32_t okm = 0;
+      uint64_t hh[RPOS];
+      if constexpr (NL == 1 && RPOS == 8) {
+        fixed21 = a.k == 21 && !a.reference_owner;  // the same for every thread
+        if (fixed21) okm = cut_run_fixed<21, 8>(L.tile, lp0, active, reinterpret_cast<uint64_t (&)[RPOS]>(rec), hh);
+      }
       KmerRun<NL> run;
-      run_begin<NL>(run, L.tile, lp0, a.k);
+      if (!fixed21) run_begin<NL>(run, L.tile, lp0, a.k);
 #pragma unroll
       for (int j = 0; j < RPOS; j++) {
         uint64_t h = 0;
         uint32_t owner = 0;
-        const bool valid = run_kmer<NL>(run, j, lp0, a.k, rec[j], h, P, a.reference_owner, &owner) && active;
-        if (j + 1 < RPOS) run_advance<NL>(run, j, lp0, a.k);
+        bool valid;
+        if (fixed21) {
+          valid = (okm >> j) & 1u;
+          owner = kc_owner_of_hash(hh[j], P);
+        } else {
+          valid = run_kmer<NL>(run, j, lp0, a.k, rec[j], h, P, a.reference_owner, &owner) && active;
+          if (j + 1 < RPOS) run_advance<NL>(run, j, lp0, a.k);
+        }
         br[j] = ~0u;
         const uint32_t b = P > 1 ? owner : 0u;
         if (P <= 16) {
@@ -1151,6 +1203,81 @@ __global__ __launch_bounds__(WGB) void kc_l1_records_kernel(const uint64_t *recs
         L.sp, sorted, nullptr, total, D, [&](const uint64_t (&r)[NL]) { return CP ? cp_b1(r[0], gm) : hash_b1(rec_hash<NL>(r), gm); },
         [&](uint32_t, const uint64_t (&r)[NL]) { l1_overflow<NL, CP>(gm, bb, cb, r); },
         [&](size_t i, const uint64_t (&r)[NL]) { store_words<NL>(D.arena, i, r); });
+    buf ^= 1;
+  }
+  if ((uint32_t)tid < P1) bb.cnt1[(size_t)g * P1 + tid] = cst.cur;
+  if (tid == 0) {
+    bb.used1[g] = min(L.sp.arena_used, gm.A1);
+    bb.used1[gm.G + g] = min(L.sp.arena_top, gm.A1);
+  }
+  for (int o = 32; o > 0; o >>= 1) n_ins += __shfl_down(n_ins, o);
+  if (lane_id() == 0 && n_ins) {
+    atomicAdd((unsigned long long *)&ctrs[CTR_INSERTED], (unsigned long long)n_ins);
+    atomicAdd((unsigned long long *)&ctrs[CTR_EXPECT], (unsigned long long)n_ins);
+  }
+}
+
+// The same for compact records in the short form (Geom::cp with 2k - la <= 32): the round's records are held as the 32 bits
+// of the mix below the bucket + bucket and extension codes, staged in six bytes and copied out in pairs, like
+// kc_l1_reads16_kernel's (split_stage_pairs / split_copy_out_pairs).
+constexpr size_t l1r16_lds_bytes() { return ((sizeof(L1RLDS) + 15) & ~size_t(15)) + (size_t)ST16_SLOTS * 6; }
+__global__ __launch_bounds__(WGB) void kc_l1_records16_kernel(const uint64_t *recs, uint64_t n, Geom gm, BucketBufs bb, uint32_t rot, uint64_t *ctrs,
+                                                              uint64_t *cb) {
+  extern __shared__ __align__(16) uint8_t smem[];
+  L1RLDS &L = *reinterpret_cast<L1RLDS *>(smem);
+  uint32_t *slo = reinterpret_cast<uint32_t *>(smem + ((sizeof(L1RLDS) + 15) & ~size_t(15)));
+  uint16_t *sbk = reinterpret_cast<uint16_t *>(slo + ST16_SLOTS);
+  const int tid = threadIdx.x;
+  const uint32_t g = (blockIdx.x + rot) % gm.G, P1 = gm.P1;
+  ChainDest D = l1_dest<1>(gm, bb, g);
+#ifdef KC_STAMPS
+  unsigned long long tprev_ = __builtin_amdgcn_s_memtime();
+  D.stamps = nullptr;
+  D.tprev = &tprev_;
+#endif
+  ChainState cst = split_load_state(L.sp, P1, bb.cnt1 + (size_t)g * P1, D.chain, D.LMAX, D.log2CH, bb.used1[g], bb.used1[gm.G + g]);
+  __syncthreads();
+  const uint64_t per_round = (uint64_t)WGB * R16;
+  const uint64_t nrounds = (n + per_round - 1) / per_round;
+  uint32_t n_ins = 0;
+  int buf = 0;
+  uint64_t nxt[R16];  // the next round's records, on their way while this round is split
+  auto load_round = [&](uint64_t rd) {  // n > 0; no branches around the loads (a lane past the end re-reads the last record)
+#pragma unroll
+    for (int j = 0; j < R16; j++) {
+      uint64_t i = rd * per_round + (uint64_t)j * WGB + tid;
+      i = i < n ? i : n - 1;
+      nxt[j] = recs[i];
+    }
+  };
+  uint32_t lo[R16], br[R16];
+  auto take_over = [&]() {  // k-mer record -> mixed record -> short form
+#pragma unroll
+    for (int j = 0; j < R16; j++) {
+      const uint64_t m = cp_mix_rec(nxt[j], gm);
+      lo[j] = (uint32_t)(m >> (64u - gm.k2));
+      br[j] = cp_b1(m, gm) | (((uint32_t)m & 63u) << 10);
+    }
+  };
+  if (n) load_round(blockIdx.x);
+  take_over();
+  if (n) load_round((uint64_t)blockIdx.x + gridDim.x);
+  for (uint64_t rd = blockIdx.x; rd < nrounds; rd += gridDim.x) {
+#pragma unroll
+    for (int j = 0; j < R16; j++) {
+      const bool valid = rd * per_round + (uint64_t)j * WGB + tid < n;
+      const uint32_t rank = hist_rank(L.sp, buf, br[j] & (PMAX - 1), valid);
+      br[j] = valid ? (br[j] | (rank << 16)) : ~0u;
+      n_ins += valid ? 1u : 0u;
+    }
+    lds_barrier();
+    const uint32_t total = split_stage_pairs(L.sp, slo, sbk, buf, P1, lo, br, D, cst, [&]() {});
+    take_over();
+    load_round(rd + 2 * (uint64_t)gridDim.x);
+    split_copy_out_pairs(L.sp, slo, sbk, total, D, gm, [&](uint64_t r) {
+      const uint64_t rr[1] = {r};
+      l1_overflow<1, true>(gm, bb, cb, rr);
+    });
     buf ^= 1;
   }
   if ((uint32_t)tid < P1) bb.cnt1[(size_t)g * P1 + tid] = cst.cur;

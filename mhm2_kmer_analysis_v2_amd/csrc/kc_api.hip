@@ -769,6 +769,13 @@ static int bk_init(kc_ctx *c) {
     }
   }
   if (g.P1 < 1 || g.P2 < 1 || g.P1 > PMAX || g.P2 > PMAX) return KC_ERR_INVALID_ARG;
+  // six-byte level-1 records: wherever the kernels that write them run -- compact records of k = 21 (MHM2's first and only
+  // one-word k of its default sweep, src/options.hpp:80) whose mix fits 32 bits below the level-1 bucket
+  // (KC_L1_ROUND16=0: the general kernels with their rounds of eight and 8-byte records, for A/B runs)
+  {
+    static const bool round16 = !(getenv("KC_L1_ROUND16") && getenv("KC_L1_ROUND16")[0] == '0');
+    g.rec6 = (c->nl == 1 && g.cp && c->k == 21 && g.k2 - g.la <= 32 && round16) ? 1u : 0u;
+  }
   // one writer per CU, but never so many that a writer's share of the buffer is below a few rounds of records
   g.G = t.writers ? std::min<uint32_t>(t.writers, GMAX)
                   : (uint32_t)std::max<uint64_t>(1, std::min<uint64_t>((uint64_t)std::min<int>(c->num_cus, GMAX), bcap / (4 * 16384)));
@@ -805,7 +812,8 @@ static int bk_init(kc_ctx *c) {
   b.ovf2_cap = t.ovf_capacity ? t.ovf_capacity : std::max<uint64_t>(bcap / (c->nl == 1 ? 32 : 64) + 4096, 2 * (uint64_t)SUPER_SPAN);
   const size_t w = (size_t)c->nl * 8;
   const size_t nseg = (size_t)g.G * g.P1;
-  const size_t rec1_bytes = (size_t)g.G * g.A1 * CH1 * w, rec2_bytes = (size_t)g.A2 * CH2 * (g.cp ? 4 : w);
+  // (+ 64: a pair of six-byte records is loaded and stored as twelve bytes, wherever in the arena it lies)
+  const size_t rec1_bytes = (size_t)g.G * g.A1 * CH1 * (g.rec6 ? 6 : w) + 64, rec2_bytes = (size_t)g.A2 * CH2 * (g.cp ? 4 : w);
   bool rec1_reused = false, rec2_reused = false;
   {
     int rc = bk_take(c, 0, (void **)&b.rec1, rec1_bytes, &rec1_reused);
@@ -947,9 +955,8 @@ static int launch_l1_reads_t(kc_ctx *c, const ExtractArgs &a, uint64_t nsuper) {
   c->gm.abl = getenv("KC_ABL_L1") ? (uint32_t)atoi(getenv("KC_ABL_L1")) : 0u;
 #endif
   if constexpr (NL == 1) {
-    // ... and its rounds of sixteen k-mers per thread (kc_l1_reads16_kernel; KC_L1_ROUND16=0: the rounds of eight, for A/B runs)
-    static const bool round16 = !(getenv("KC_L1_ROUND16") && getenv("KC_L1_ROUND16")[0] == '0');
-    if (use_cp<NL>(c) && k21 && round16) {
+    // ... and its rounds of sixteen k-mers per thread, six-byte records (kc_l1_reads16_kernel; Geom::rec6)
+    if (c->gm.rec6) {
       auto kern16 = sh ? kc_l1_reads16_kernel<FMT, true, 21> : kc_l1_reads16_kernel<FMT, false, 21>;
       int rc16 = set_dyn_lds(kern16, l1x16_lds_bytes());
       if (rc16) return rc16;
@@ -1053,7 +1060,7 @@ static int launch_l1_records_t(kc_ctx *c, const uint64_t *recs, uint64_t n) {
   const unsigned grid = (unsigned)std::min<uint64_t>(c->gm.G, (n + per_round - 1) / per_round);
   if constexpr (NL == 1) {
     static_assert(Rnd<1>::RPOS == R16, "both kernels take sixteen records per thread and round");
-    if (use_cp<NL>(c) && c->gm.k2 - c->gm.la <= 32) {  // short form: 6-byte staging, pair stores (kc_l1_records16_kernel)
+    if (c->gm.rec6) {  // short form: 6-byte staging, pair stores, six-byte records (kc_l1_records16_kernel)
       int rc16 = set_dyn_lds(kc_l1_records16_kernel, l1r16_lds_bytes());
       if (rc16) return rc16;
       KernelTimer kt(c, KT_L1_RECORDS);
@@ -2315,7 +2322,10 @@ static int bk_level2_launch(kc_ctx *c, bool inc) {
               : use_cp<NL>(c) ? (cr ? (fl ? kc_l2_split_kernel<NL, NL == 1, NL == 1, true> : kc_l2_split_kernel<NL, NL == 1, NL == 1, false>)
                                     : (fl ? kc_l2_split_kernel<NL, NL == 1, false, true> : kc_l2_split_kernel<NL, NL == 1, false, false>))
                               : (fl ? kc_l2_split_kernel<NL, false, false, true> : kc_l2_split_kernel<NL, false, false, false>);
-  int rc = set_dyn_lds(kern, lds_l2<NL>());
+  // six-byte level-1 records have a level 2 of their own (kc_l2_rec6_kernel)
+  const bool r6 = NL == 1 && c->gm.rec6 != 0;
+  auto kern6 = inc ? kc_l2_rec6_kernel<false, true> : (fl ? kc_l2_rec6_kernel<true, false> : kc_l2_rec6_kernel<false, false>);
+  int rc = r6 ? set_dyn_lds(kern6, l2r6_lds_bytes()) : set_dyn_lds(kern, lds_l2<NL>());
   if (rc) return rc;
   FlatSrc fs;
   memset(&fs, 0, sizeof(fs));
@@ -2345,8 +2355,9 @@ static int bk_level2_launch(kc_ctx *c, bool inc) {
 #endif
   if (fs.b_hi > fs.b_lo) {
     KernelTimer kt(c, KT_L2_SPLIT);
-    hipLaunchKernelGGL(kern, dim3(std::min<unsigned>(fs.b_hi - fs.b_lo, (unsigned)c->num_cus)), dim3(WGB), lds_l2<NL>(), c->stream, c->gm, c->bb,
-                       fs, c->d_cb);
+    const dim3 grid(std::min<unsigned>(fs.b_hi - fs.b_lo, (unsigned)c->num_cus));
+    if (r6) hipLaunchKernelGGL(kern6, grid, dim3(WGB), l2r6_lds_bytes(), c->stream, c->gm, c->bb, fs, c->d_cb);
+    else hipLaunchKernelGGL(kern, grid, dim3(WGB), lds_l2<NL>(), c->stream, c->gm, c->bb, fs, c->d_cb);
   }
   HIPCHK(hipGetLastError());
   return KC_OK;

@@ -68,6 +68,12 @@ struct Geom {
   uint32_t la, lb;             // log2 P1, log2 P2
   uint32_t k2;                 // 2k: bits of the mixed k-mer
   uint32_t own_lo, own_hi;     // level-1 buckets this shard owns (every one unless the context is in the shard flow): ChainDest::own_lo
+  // Level-1 records of SIX bytes (the kernels that stage the short form of compact records, kc_l1_reads16_kernel and
+  // kc_l1_records16_kernel, write nothing else): the 32 bits of the mix below the bucket, then bucket | extension codes << 10
+  // in 16 bits -- what the staging holds; the bucket is the chain's anyway.  A chunk is CH1 records of six bytes.  Two
+  // records are one 12-byte store for the writer and one aligned 12-byte load for level 2 (kc_l2_rec6_kernel): a third more
+  // records per second than 8-byte ones on either side (scripts/ubench_rec6.hip, profiles/r04_ubench_rec6.txt).
+  uint32_t rec6;
 #ifdef KC_ABLATE
   uint32_t abl;                // experiment builds (-DKC_ABLATE): which part of a kernel to leave out (scripts/ablate.py)
 #endif
@@ -520,6 +526,13 @@ __device__ __forceinline__ ChainDest l1_dest(const Geom &gm, const BucketBufs &b
   return D;
 }
 
+// the same for a geometry of six-byte level-1 records (Geom::rec6): the writer's part starts at that many BYTES
+__device__ __forceinline__ ChainDest l1_dest6(const Geom &gm, const BucketBufs &bb, uint32_t g) {
+  ChainDest D = l1_dest<1>(gm, bb, g);
+  D.arena = reinterpret_cast<uint64_t *>(reinterpret_cast<uint8_t *>(bb.rec1) + (((size_t)g * gm.A1) << gm.log2CH1) * 6);
+  return D;
+}
+
 // the overflow lists always hold k-mer records (the global-table kernels read them), never mixed ones
 template <int NL, bool CP>
 __device__ __forceinline__ void l1_overflow(const Geom &gm, const BucketBufs &bb, uint64_t *cb, const uint64_t (&r)[NL]) {
@@ -853,10 +866,16 @@ __device__ __forceinline__ uint32_t split_stage_pairs(SplitLDS &L, uint32_t *slo
   return total;
 }
 
-// two staged records (one destination) as one 16-byte store; the address is 8-byte aligned
-struct __attribute__((aligned(8))) RecPair {
-  uint64_t a, b;
+// two staged records (one destination) as one 12-byte store; the address is a multiple of six, i.e. 2-byte aligned
+// (three words put together by hand: of a struct with 16-bit members the compiler makes four or five narrow stores)
+struct __attribute__((packed, aligned(2))) Rec6Pair {
+  uint32_t w0, w1, w2;  // lo0 | bk0, lo1's low half << 16 | lo1's high half, bk1 << 16
 };
+struct __attribute__((packed, aligned(2))) Rec6 {
+  uint32_t lo;
+  uint16_t bk;
+};
+static_assert(sizeof(Rec6Pair) == 12 && sizeof(Rec6) == 6, "six bytes a record");
 
 template <class OvfFn>
 __device__ __forceinline__ void split_copy_out_pairs(SplitLDS &L, const uint32_t *slo, const uint16_t *sbk, uint32_t total, const ChainDest &D,
@@ -866,8 +885,9 @@ __device__ __forceinline__ void split_copy_out_pairs(SplitLDS &L, const uint32_t
 #define KC_COPY_U 2
 #endif
   constexpr int U = KC_COPY_U;  // pairs per thread and trip: first all their records, then all their destinations, then the stores
-  uint64_t *const arena0 = D.arena + ((size_t)D.arena_base << D.log2CH);
-  const uint32_t shb = 32u - gm.la, shl = 64u - gm.k2;  // the bucket in the high word; the 32 bits below it start here (shl < 32)
+  // (D.arena: the owner's part of the level-1 arena in six-byte records, l1_dest6)
+  uint8_t *const arena0 = reinterpret_cast<uint8_t *>(D.arena) + ((size_t)D.arena_base << D.log2CH) * 6;
+  const uint32_t shb = 32u - gm.la, shl = 64u - gm.k2;  // (the record as a 64-bit mixed one, for the overflow list only)
   for (uint32_t i0 = 2u * (uint32_t)tid; i0 < total; i0 += 2u * U * WGB) {
     uint64_t lo2[U];
     uint32_t bk2[U];
@@ -890,14 +910,20 @@ __device__ __forceinline__ void split_copy_out_pairs(SplitLDS &L, const uint32_t
       const bool f0 = live && j < fit, real1 = live && j + 1u < v, f1 = real1 && j + 1u < fit;
       // x and y are "index minus staging position" modulo 2^32: the sums must wrap in 32 bits before they are widened
       const uint32_t at0 = (j < wold ? d[u].x : d[u].y) + i, at1 = (j + 1u < wold ? d[u].x : d[u].y) + i + 1u;
-      const uint32_t l0 = (uint32_t)lo2[u], l1 = (uint32_t)(lo2[u] >> 32);
-      const uint32_t bh = (bk2[u] & (PMAX - 1)) << shb;
-      RecPair r;
-      r.a = ((uint64_t)(bh | (l0 >> (32u - shl))) << 32) | (uint64_t)((l0 << shl) | ((bk2[u] >> 10) & 63u));
-      r.b = ((uint64_t)(bh | (l1 >> (32u - shl))) << 32) | (uint64_t)((l1 << shl) | (bk2[u] >> 26));
       const bool pair = f0 && f1 && at1 == at0 + 1u;
-      if (pair) *reinterpret_cast<RecPair *>(arena0 + at0) = r;
-      else if (f0) arena0[at0] = r.a;
+      if (pair) {
+        const uint32_t l1 = (uint32_t)(lo2[u] >> 32);
+        Rec6Pair r;
+        r.w0 = (uint32_t)lo2[u];
+        r.w1 = (bk2[u] & 0xFFFFu) | (l1 << 16);
+        r.w2 = (l1 >> 16) | (bk2[u] & 0xFFFF0000u);
+        *reinterpret_cast<Rec6Pair *>(arena0 + (size_t)at0 * 6) = r;
+      } else if (f0) {
+        Rec6 r;
+        r.lo = (uint32_t)lo2[u];
+        r.bk = (uint16_t)bk2[u];
+        *reinterpret_cast<Rec6 *>(arena0 + (size_t)at0 * 6) = r;
+      }
       odd |= (real1 && !pair) || (live && !f0);
     }
     if (__any(odd)) {  // seldom: a pair across two chunks of its chain; a full chain or arena
@@ -914,8 +940,14 @@ __device__ __forceinline__ void split_copy_out_pairs(SplitLDS &L, const uint32_t
         const bool f0 = j < fit, real1 = j + 1u < v, f1 = real1 && j + 1u < fit;
         if (!f0) overflow(ra);
         if (real1 && !(f0 && f1 && at1 == at0 + 1u)) {
-          if (f1) arena0[at1] = rb;
-          else overflow(rb);
+          if (f1) {
+            Rec6 r;
+            r.lo = l1;
+            r.bk = (uint16_t)(bk2[u] >> 16);
+            *reinterpret_cast<Rec6 *>(arena0 + (size_t)at1 * 6) = r;
+          } else {
+            overflow(rb);
+          }
         }
       }
     }
@@ -932,7 +964,7 @@ __global__ __launch_bounds__(WGB) void kc_l1_reads16_kernel(ExtractArgs a, Geom 
   uint16_t *sbk = reinterpret_cast<uint16_t *>(slo + ST16_SLOTS);
   const int tid = threadIdx.x;
   const uint32_t g = (blockIdx.x + rot) % gm.G, P1 = gm.P1;
-  ChainDest D = l1_dest<1>(gm, bb, g);
+  ChainDest D = l1_dest6(gm, bb, g);
 #ifdef KC_STAMPS
   unsigned long long tprev_ = __builtin_amdgcn_s_memtime();
   D.stamps = cb + 8;
@@ -1229,7 +1261,7 @@ __global__ __launch_bounds__(WGB) void kc_l1_records16_kernel(const uint64_t *re
   uint16_t *sbk = reinterpret_cast<uint16_t *>(slo + ST16_SLOTS);
   const int tid = threadIdx.x;
   const uint32_t g = (blockIdx.x + rot) % gm.G, P1 = gm.P1;
-  ChainDest D = l1_dest<1>(gm, bb, g);
+  ChainDest D = l1_dest6(gm, bb, g);
 #ifdef KC_STAMPS
   unsigned long long tprev_ = __builtin_amdgcn_s_memtime();
   D.stamps = nullptr;
@@ -1297,6 +1329,14 @@ template <int NL>
 __device__ __forceinline__ const uint64_t *l1_record(const Geom &gm, const BucketBufs &bb, uint32_t g, uint32_t b, uint32_t i) {
   const uint32_t chunk = bb.chain1[((size_t)g * gm.P1 + b) * gm.L1MAX + (i >> gm.log2CH1)];
   return bb.rec1 + (((((size_t)g * gm.A1) + chunk) << gm.log2CH1) + (i & ((1u << gm.log2CH1) - 1u))) * NL;
+}
+
+// the same in a geometry of six-byte records, as the 64-bit mixed record it stands for
+__device__ __forceinline__ uint64_t l1_record6(const Geom &gm, const BucketBufs &bb, uint32_t g, uint32_t b, uint32_t i) {
+  const uint32_t chunk = bb.chain1[((size_t)g * gm.P1 + b) * gm.L1MAX + (i >> gm.log2CH1)];
+  const uint8_t *p = reinterpret_cast<const uint8_t *>(bb.rec1) + (((((size_t)g * gm.A1) + chunk) << gm.log2CH1) + (i & ((1u << gm.log2CH1) - 1u))) * 6;
+  const Rec6 r = *reinterpret_cast<const Rec6 *>(p);
+  return ((uint64_t)b << (64u - gm.la)) | ((uint64_t)r.lo << (64u - gm.k2)) | (uint64_t)((r.bk >> 10) & 63u);
 }
 
 // record i of region r's chain
@@ -1552,6 +1592,195 @@ __global__ __launch_bounds__(WGB) void kc_l2_split_kernel(Geom gm, BucketBufs bb
       if ((uint32_t)tid < P2) bb.cnt2[(size_t)b1 * P2 + tid] = cst.cur;
       if constexpr (INC) {
         if ((uint32_t)tid < G) bb.done1[(size_t)tid * P1 + b1] = L.skip[tid] + (L.pre[tid + 1] - L.pre[tid]);
+        if (tid == 0) bb.used2[b1] = min(L.sp.arena_used, D.arena_cap);
+      }
+    }
+    __syncthreads();
+  }
+}
+
+// ---- level 2 over six-byte level-1 records (Geom::rec6) -----------------------------------------------------------------
+// The walk, the rounds, the staging and the copy-out of kc_l2_split_kernel<1, true, true, ...>; what differs is how a round's
+// records arrive.  A thread takes them two at a time: a bucket's segments (its G chains, then its flat sources) are laid
+// end to end with every segment starting at an EVEN in-chain index and padded to an even length, so that a pair of slots
+// never straddles two segments or two chunks and a pair of a chain is ONE aligned 12-byte load (a third more records per
+// second than 8-byte records one per lane, scripts/ubench_rec6.hip); a slot that holds no record of this pass -- the pad
+// behind an odd segment; with instalments the record in front of an odd start, which an earlier instalment took -- is a
+// bit in the thread's mask.  A pair of a flat source is the 10 bytes of two wire records (kc_shard.hpp) in one unaligned
+// 12-byte load.
+struct L2R6LDS {
+  SplitLDS sp;
+  uint32_t pre[GMAX + 1];  // prefix of the segments' padded lengths, in slots
+  uint32_t end[GMAX];      // a segment's true end: records in the chain (in the flat source)
+  union {
+    uint64_t flo[FLAT_MAX];  // shard flow: where the bucket's run starts in each flat source
+    uint32_t skip[GMAX];     // INC: records at the head of each chain that an earlier instalment has taken
+  };
+};
+constexpr size_t l2r6_lds_bytes() { return ((sizeof(L2R6LDS) + 15) & ~size_t(15)) + Rnd<1>::STAGE; }
+static_assert(l2r6_lds_bytes() <= 160 * 1024, "level 2's working set fits the LDS");
+struct __attribute__((packed, aligned(2))) Load12 {
+  uint32_t a, b, c;
+};
+
+template <bool FL, bool INC>
+__global__ __launch_bounds__(WGB) void kc_l2_rec6_kernel(Geom gm, BucketBufs bb, FlatSrc fs, uint64_t *cb) {
+  static_assert(!(INC && FL), "instalments are for a context that is not in the shard flow");
+  extern __shared__ __align__(16) uint8_t smem[];
+  L2R6LDS &L = *reinterpret_cast<L2R6LDS *>(smem);
+  uint64_t *sorted = reinterpret_cast<uint64_t *>(smem + ((sizeof(L2R6LDS) + 15) & ~size_t(15)));
+  constexpr int RPOS = 16, NPAIR = 8;
+  const int tid = threadIdx.x;
+  const uint32_t P1 = gm.P1, P2 = gm.P2, G = gm.G;
+  const uint32_t GT = FL ? G + fs.F : G;  // segments of a bucket
+  const uint32_t CH1m = (1u << gm.log2CH1) - 1u;
+  const uint8_t *const rec1 = reinterpret_cast<const uint8_t *>(bb.rec1);
+  for (uint32_t b1 = (FL ? fs.b_lo : 0u) + blockIdx.x; b1 < (FL ? fs.b_hi : P1); b1 += gridDim.x) {
+    {
+      const int tid = fresh_tid();
+      uint32_t v = 0;
+      if ((uint32_t)tid < G) {
+        const uint32_t cnt = bb.cnt1[(size_t)tid * P1 + b1];
+        uint32_t d = 0;
+        if constexpr (INC) {
+          d = bb.done1[(size_t)tid * P1 + b1];
+          L.skip[tid] = d;
+        }
+        L.end[tid] = cnt;
+        v = cnt > d ? ((cnt - (d & ~1u) + 1u) & ~1u) : 0u;  // slots: from the even index at or below the first record to an even end
+      }
+      if constexpr (FL) {
+        if ((uint32_t)tid >= G && (uint32_t)tid < GT) {
+          const uint32_t c = fs.cnt[(size_t)(tid - G) * fs.nbo + (b1 - fs.b_lo)];
+          L.flo[tid - G] = fs.at[(size_t)(tid - G) * fs.nbo + (b1 - fs.b_lo)];
+          L.end[tid] = c;
+          v = (c + 1u) & ~1u;
+        }
+      }
+      const uint32_t e = block_excl_scan(v, L.sp.scan);
+      if ((uint32_t)tid < GT) L.pre[tid] = e;
+      if (tid == 0) L.pre[GT] = L.sp.scan.total;
+    }
+    ChainDest D;
+    D.arena = bb.rec2;
+    D.chain = bb.chain2 + (size_t)b1 * P2 * gm.L2MAX;
+    D.log2CH = gm.log2CH2;
+    D.LMAX = gm.L2MAX;
+    D.arena_base = bb.base2[b1];
+    D.arena_cap = bb.base2[b1 + 1] - bb.base2[b1];
+    D.own_lo = 0;
+    D.own_hi = PMAX;
+#ifdef KC_ABLATE
+    D.abl = gm.abl;
+    D.abl_a = 16;
+#endif
+#ifdef KC_STAMPS
+    unsigned long long tprev_ = __builtin_amdgcn_s_memtime();
+    D.stamps = cb + 8;
+    D.tprev = &tprev_;
+#endif
+    ChainState cst = split_load_state(L.sp, P2, INC ? bb.cnt2 + (size_t)b1 * P2 : nullptr, D.chain, D.LMAX, D.log2CH, INC ? bb.used2[b1] : 0u);
+    __syncthreads();
+    const uint32_t n = L.pre[GT];  // slots of the bucket (even)
+    const uint32_t per_round = WGB * RPOS;
+    uint32_t p_ids = 0, p_rec = 0;  // segment cursors of this thread, one per pass (their indices only grow)
+    Load12 nxt[NPAIR];
+    uint32_t nxt_valid = 0, nxt_flat = 0;  // bit s: slot s of the thread holds a record; bit j: pair j came from a flat source
+    // no branches around the loads (a lane past the end re-reads the bucket's last pair)
+    auto load_round = [&](uint32_t v0) {  // n > 0
+      uint32_t ids[NPAIR];
+#pragma unroll
+      for (int j = 0; j < NPAIR; j++) {
+        const uint32_t e = min(v0 + 2u * ((uint32_t)j * WGB + tid), n - 2u);
+        while (e >= L.pre[p_ids + 1]) p_ids++;
+        // (a pair of a flat source needs no chunk id: it re-reads the table's first word, no branch)
+        const uint32_t i0 = e - L.pre[p_ids] + (INC ? (L.skip[p_ids] & ~1u) : 0u);
+        const size_t ci = ((size_t)p_ids * gm.P1 + b1) * gm.L1MAX + (i0 >> gm.log2CH1);
+        ids[j] = bb.chain1[FL && p_ids >= G ? 0 : ci];
+      }
+      nxt_valid = 0;
+#pragma unroll
+      for (int j = 0; j < NPAIR; j++) {
+        const uint32_t ev = v0 + 2u * ((uint32_t)j * WGB + tid), e = min(ev, n - 2u);
+        while (e >= L.pre[p_rec + 1]) p_rec++;
+        const bool flat = FL && p_rec >= G;
+        const uint32_t first = (INC && !flat) ? L.skip[p_rec] : 0u;
+        const uint32_t i0 = e - L.pre[p_rec] + (first & ~1u), end = L.end[p_rec];
+        const uint8_t *src = rec1 + ((((size_t)p_rec * gm.A1 + ids[j]) << gm.log2CH1) + (i0 & CH1m)) * 6;
+        if constexpr (FL) {
+          const uint64_t f0 = L.flo[flat ? p_rec - G : 0u];
+          if (flat) src = reinterpret_cast<const uint8_t *>((uintptr_t)f0) + 5u * (size_t)i0;
+          nxt_flat = flat ? (nxt_flat | (1u << j)) : (nxt_flat & ~(1u << j));
+        }
+        const bool in = ev < n;
+        nxt_valid |= (in && i0 >= first && i0 < end ? 1u : 0u) << (2 * j);
+        nxt_valid |= (in && i0 + 1u < end ? 2u : 0u) << (2 * j);  // (i0 + 1 >= first always: first <= i0 + 1)
+        nxt[j] = *reinterpret_cast<const Load12 *>(src);
+      }
+    };
+    // lo + br: this round's records in the short form; nxt: the next round's, taken over in the middle of the round
+    uint32_t lo[RPOS], br[RPOS];
+    uint32_t cur_valid = 0;
+    const uint32_t sh_b2 = gm.k2 - gm.la - gm.lb;  // where the region's index starts in the mix
+    auto take_over = [&]() {
+#pragma unroll
+      for (int j = 0; j < NPAIR; j++) {
+        const Load12 w = nxt[j];
+        uint32_t e0, e1;
+        if (FL && ((nxt_flat >> j) & 1u)) {  // two wire records: 4 + 1 bytes each
+          lo[2 * j] = w.a;
+          e0 = w.b & 63u;
+          lo[2 * j + 1] = (w.b >> 8) | (w.c << 24);
+          e1 = (w.c >> 8) & 63u;
+        } else {  // two level-1 records: 4 + 2 bytes each, the extension codes above the bucket's ten bits
+          lo[2 * j] = w.a;
+          e0 = (w.b >> 10) & 63u;
+          lo[2 * j + 1] = (w.b >> 16) | (w.c << 16);
+          e1 = w.c >> 26;
+        }
+        br[2 * j] = ((lo[2 * j] >> sh_b2) & (P2 - 1u)) | (e0 << 10);
+        br[2 * j + 1] = ((lo[2 * j + 1] >> sh_b2) & (P2 - 1u)) | (e1 << 10);
+      }
+      cur_valid = nxt_valid;
+    };
+    if (n) load_round(0);
+    take_over();
+    if (per_round < n) load_round(per_round);
+    int buf = 0;
+    for (uint32_t v0 = 0; v0 < n; v0 += per_round) {
+#pragma unroll
+      for (int j = 0; j < RPOS; j++) {
+        const bool valid = (cur_valid >> j) & 1u;
+        const uint32_t rank = hist_rank(L.sp, buf, br[j] & (PMAX - 1), valid);
+        br[j] = valid ? (br[j] | (rank << 16)) : ~0u;
+      }
+      KC_SPLIT_STAMP(0)  // histogram
+      lds_barrier();
+      const uint32_t total = split_stage<1, RPOS, 16>(
+          L.sp, sorted, nullptr, buf, P2,
+          [&](int j, uint64_t (&o)[1]) {
+            o[0] = ((uint64_t)b1 << (64u - gm.la)) | ((uint64_t)lo[j] << (64u - gm.k2)) | (uint64_t)((br[j] >> 10) & 63u);
+          },
+          br, D, cst);
+      take_over();
+      if (v0 + 2 * (uint64_t)per_round < n) load_round(v0 + 2 * per_round);
+      KC_SPLIT_STAMP(5)  // take over the next round's records, request the one after
+      split_copy_out<1>(
+          L.sp, sorted, nullptr, total, D, [&](const uint64_t (&r)[1]) { return cp_b2(r[0], gm); },
+          [&](uint32_t b, const uint64_t (&r)[1]) {
+            bb.flag[(size_t)b1 * P2 + b] = 1;
+            const uint64_t o = atomicAdd((unsigned long long *)&cb[CB_OVF2], 1ULL);
+            if (o < bb.ovf2_cap) bb.ovf2[o] = cp_unmix_rec(r[0], gm);
+            else atomicOr((unsigned long long *)&cb[CB_FATAL], (unsigned long long)FATAL_OVF2);
+          },
+          [&](size_t i, const uint64_t (&r)[1]) { reinterpret_cast<uint32_t *>(D.arena)[i] = cp_pack32(r[0], gm); });
+      buf ^= 1;
+    }
+    {
+      const int tid = fresh_tid();
+      if ((uint32_t)tid < P2) bb.cnt2[(size_t)b1 * P2 + tid] = cst.cur;
+      if constexpr (INC) {
+        if ((uint32_t)tid < G) bb.done1[(size_t)tid * P1 + b1] = L.end[tid];  // every record of the chain has been to level 2 now
         if (tid == 0) bb.used2[b1] = min(L.sp.arena_used, D.arena_cap);
       }
     }
@@ -2439,9 +2668,13 @@ __global__ __launch_bounds__(TPB) void kc_l1_to_table_kernel(Geom gm, BucketBufs
     const uint32_t n = bb.cnt1[sgi];
     const uint32_t g = (uint32_t)(sgi / gm.P1), b = (uint32_t)(sgi % gm.P1);
     for (uint32_t i = threadIdx.x; i < n; i += TPB) {
-      const uint64_t *src = l1_record<NL>(gm, bb, g, b, i);
       uint64_t rec[NL];
-      for (int w = 0; w < NL; w++) rec[w] = src[w];
+      if (NL == 1 && CP && gm.rec6) {
+        rec[0] = l1_record6(gm, bb, g, b, i);
+      } else {
+        const uint64_t *src = l1_record<NL>(gm, bb, g, b, i);
+        for (int w = 0; w < NL; w++) rec[w] = src[w];
+      }
       if (CP) rec[0] = cp_unmix_rec(rec[0], gm);
       table_insert<NL>(t, rec, ctrs);
     }

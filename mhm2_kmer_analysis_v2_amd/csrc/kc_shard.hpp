@@ -140,10 +140,18 @@ __global__ __launch_bounds__(WGB) void kc_shard_pack_kernel(Geom gm, BucketBufs 
     for (uint32_t i = tid; i < cnt; i += WGB) {
       const uint64_t *src = arena + (((size_t)chain[i >> gm.log2CH1] << gm.log2CH1) + (i & CHm)) * NL;
       if constexpr (WIRE5) {
-        const uint64_t r = src[0];  // mix << (64 - k2) | extension codes
         WireRec5 w;
-        w.lo = (uint32_t)(r >> (64u - gm.k2));
-        w.ext = (uint8_t)(r & KC_EXT_MASK);
+        if (gm.rec6) {  // six-byte level-1 records (Geom::rec6): the same 32 bits, the extension codes above the bucket's ten
+          const uint8_t *p6 = reinterpret_cast<const uint8_t *>(bb.rec1) +
+                              (((((size_t)g * gm.A1) + chain[i >> gm.log2CH1]) << gm.log2CH1) + (i & CHm)) * 6;
+          const Rec6 r6 = *reinterpret_cast<const Rec6 *>(p6);
+          w.lo = r6.lo;
+          w.ext = (uint8_t)((r6.bk >> 10) & 63u);
+        } else {
+          const uint64_t r = src[0];  // mix << (64 - k2) | extension codes
+          w.lo = (uint32_t)(r >> (64u - gm.k2));
+          w.ext = (uint8_t)(r & KC_EXT_MASK);
+        }
         out5[i] = w;
       } else {
 #pragma unroll

@@ -2290,6 +2290,32 @@ __global__ __launch_bounds__(WGB, 8) void kc_count_kernel(Geom gm, BucketBufs bb
 #define KC_BATCH 2
 #endif
       constexpr int BATCH = NL == 1 ? KC_BATCH : NL == 2 ? 4 : 2;
+#ifndef KC_COUNT_NO_PAIRS
+      if constexpr (NL == 1 && CP) {
+        // Compact records: a lane takes TWO neighbouring records with one 8-byte load (the order in which a region's
+        // records are counted is free): one chunk id, one address, one load instruction for two records.  A chunk holds an
+        // even number of records, so the pair lies in one chunk.
+        uint32_t failed = 0;
+        for (uint32_t i0 = 0; i0 < n; i0 += 2u * WGB) {
+          uint32_t i = i0 + 2u * (uint32_t)tid;
+          const bool v0 = i < n, v1 = i + 1u < n;
+          i = v0 ? i : 0u;
+          const size_t at = ((size_t)T.chain[buf][i >> gm.log2CH2] << gm.log2CH2) + (i & CHm);
+          const uint2 rr = *reinterpret_cast<const uint2 *>(reinterpret_cast<const uint32_t *>(bb.rec2) + at);
+          if (__builtin_amdgcn_ballot_w64(v0) == 0 || KC_ABL(gm, 2)) continue;  // past the end of the region for the whole wave
+#pragma unroll
+          for (int j = 0; j < 2; j++) {
+            const bool v = j ? v1 : v0;
+            const uint32_t r0 = j ? rr.y : rr.x, key = r0 >> 6;
+            const uint32_t s = lds_probe32(keys32, S - 1u, key, key & (S - 1u), ((key >> tb.lgS) << 1) | 1u, v, failed);
+            const uint32_t le = r0 & 7u, re = (r0 >> 3) & 7u;
+            // only lanes that hold a record touch the counters: 64 atomic adds of zero to one LDS word are serialised
+            if (v && !KC_ABL(gm, 1)) ext_count<EW>(tb, s, le, re);
+          }
+        }
+        if (failed) T.fail[buf] = 1;
+      } else
+#endif
       for (uint32_t i0 = 0; i0 < n; i0 += WGB * BATCH) {
         uint64_t rec[BATCH][NL];
         uint32_t rec32[BATCH];

@@ -28,12 +28,13 @@ PROFILE = "profiles/r04_pmc_50Mreads.json"  # rocprofv3 PMC passes of this same 
 def own_alg_bytes(kernel, nl, k, read_len, results_per_raw):
     """Algorithmic HBM bytes per raw k-mer of ONE kernel of this design: what that kernel must
     read and write at least, so that its fraction of the roofline cannot exceed 1.  Compact records (k <= 23): level 1
-    writes 8-byte records, level 2 turns them into 4-byte ones."""
-    rec1 = 8.0 * nl
+    writes 8-byte records -- 6-byte ones where the remainder below the bucket fits 32 bits (kc_l1_reads16_kernel /
+    kc_l2_rec6_kernel, k = 21) -- and level 2 turns them into 4-byte ones."""
+    rec1 = 6.0 if ("l1_reads16" in kernel or "l2_rec6" in kernel) else 8.0 * nl
     rec2 = 4.0 if (nl == 1 and k <= 23) else 8.0 * nl
     if "l1_reads" in kernel:
         return 2.0 * read_len / (read_len - k + 1) + rec1   # bases + qualities in, level-1 records out
-    if "l2_split" in kernel:
+    if "l2_split" in kernel or "l2_rec6" in kernel:
         return rec1 + rec2
     if "count_kernel" in kernel:
         return rec2 + results_per_raw * (8.0 * nl + 4.0)    # region records in, dense results out

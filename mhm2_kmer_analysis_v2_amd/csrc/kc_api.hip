@@ -39,12 +39,12 @@ static int hip_fail(hipError_t e, const char *what, int line) {
   } while (0)
 
 enum { KT_EXTRACT_INSERT = 0, KT_EXTRACT_BIN, KT_INSERT_RECORDS, KT_FINALIZE, KT_TILE_FIRST, KT_REHASH, KT_L1_READS, KT_L1_RECORDS,
-       KT_L2_SPLIT, KT_COUNT_REGIONS, KT_FALLBACK, KT_SHARD_PACK, KT_L1_READS_UQ, KT_L1_READS16, KT_COUNT };
+       KT_L2_SPLIT, KT_COUNT_REGIONS, KT_FALLBACK, KT_SHARD_PACK, KT_L1_READS_UQ, KT_L1_READS16, KT_L2_REC6, KT_COUNT };
 static const char *const kt_names[KT_COUNT] = {"kc_extract_kernel<insert>", "kc_bin_reads_kernel", "kc_insert_records_kernel",
                                                "kc_finalize_kernel", "kc_tile_first_kernel", "kc_rehash_kernel",
                                                "kc_l1_reads_kernel", "kc_l1_records_kernel", "kc_l2_split_kernel",
                                                "kc_count_kernel", "kc_flagged_to_table_kernel", "kc_shard_pack_kernel",
-                                               "kc_l1_reads_kernel<byte-loaded qualities>", "kc_l1_reads16_kernel"};
+                                               "kc_l1_reads_kernel<byte-loaded qualities>", "kc_l1_reads16_kernel", "kc_l2_rec6_kernel"};
 struct kt_pending {
   hipEvent_t start, stop;
   int kind;
@@ -2354,7 +2354,7 @@ static int bk_level2_launch(kc_ctx *c, bool inc) {
   c->gm.abl = getenv("KC_ABL_L2") ? (uint32_t)atoi(getenv("KC_ABL_L2")) : 0u;
 #endif
   if (fs.b_hi > fs.b_lo) {
-    KernelTimer kt(c, KT_L2_SPLIT);
+    KernelTimer kt(c, r6 ? KT_L2_REC6 : KT_L2_SPLIT);
     const dim3 grid(std::min<unsigned>(fs.b_hi - fs.b_lo, (unsigned)c->num_cus));
     if (r6) hipLaunchKernelGGL(kern6, grid, dim3(WGB), l2r6_lds_bytes(), c->stream, c->gm, c->bb, fs, c->d_cb);
     else hipLaunchKernelGGL(kern, grid, dim3(WGB), lds_l2<NL>(), c->stream, c->gm, c->bb, fs, c->d_cb);

@@ -7,7 +7,7 @@ done
 for r in $(seq $N); do for e in "$@"; do env $e timeout -k 10 300 python bench.py --k $K --reads $READS --steps 3 --warmup 1 --cpu-sample-reads 0 --no-end-to-end 2>/dev/null | python -c "
 import sys,json
 d=json.loads(sys.stdin.readlines()[-1]); k=d['roofline']['kernels_ms']
-print('[$e]', round(d['ms_per_step'],2), round(k.get('kc_l1_reads_kernel',0)+k.get('kc_l1_reads16_kernel',0),2), round(k.get('kc_l2_split_kernel',0),2), round(k.get('kc_count_kernel',0),2), d['results']['total_kmers'])" || exit 1; done; done | tee /tmp/abe.$$
+print('[$e]', round(d['ms_per_step'],2), round(k.get('kc_l1_reads_kernel',0)+k.get('kc_l1_reads16_kernel',0),2), round(k.get('kc_l2_split_kernel',0)+k.get('kc_l2_rec6_kernel',0),2), round(k.get('kc_count_kernel',0),2), d['results']['total_kmers'])" || exit 1; done; done | tee /tmp/abe.$$
 python - <<PY
 import collections,statistics
 rows=collections.defaultdict(list)

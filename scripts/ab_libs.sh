@@ -5,7 +5,7 @@ if [ "$1" = "-n" ]; then N=$2; shift 2; fi
 for r in $(seq $N); do for l in "$@"; do KC_LIB=$PWD/$l timeout -k 10 300 python bench.py --steps 3 --warmup 1 --cpu-sample-reads 0 --no-end-to-end 2>/dev/null | python -c "
 import sys,json
 d=json.loads(sys.stdin.readlines()[-1]); k=d['roofline']['kernels_ms']
-print('$l', round(d['ms_per_step'],2), round(k.get('kc_l1_reads_kernel',0)+k.get('kc_l1_reads16_kernel',0),2), round(k.get('kc_l2_split_kernel',0),2), round(k.get('kc_count_kernel',0),2), d['results']['total_kmers'])" || exit 1; done; done | tee /tmp/ab.$$ 
+print('$l', round(d['ms_per_step'],2), round(k.get('kc_l1_reads_kernel',0)+k.get('kc_l1_reads16_kernel',0),2), round(k.get('kc_l2_split_kernel',0)+k.get('kc_l2_rec6_kernel',0),2), round(k.get('kc_count_kernel',0),2), d['results']['total_kmers'])" || exit 1; done; done | tee /tmp/ab.$$ 
 python - <<PY
 import collections,statistics
 rows=collections.defaultdict(list)

@@ -17,7 +17,7 @@ def context():
     return kc
 kc = context()
 kc.synth_reads_device(b, q, o, n, first_read=0, params=pkg.synth_params())
-names = {"KC_ABL_L1": "kc_l1_reads16_kernel", "KC_ABL_L2": "kc_l2_split_kernel", "KC_ABL_COUNT": "kc_count_kernel"}
+names = {"KC_ABL_L1": "kc_l1_reads16_kernel", "KC_ABL_L2": "kc_l2_rec6_kernel", "KC_ABL_COUNT": "kc_count_kernel"}
 what = {1: "no global stores / no counter adds", 2: "no copy-out / no probes", 3: "no scatter, no copy-out / no vote + write", 4: "runs forced to whole aligned 64-byte blocks"}
 def step(kc, finalize=True):
     kc.reset(); kc.kernel_times(clear=True)

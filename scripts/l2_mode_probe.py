@@ -23,6 +23,6 @@ for r in range(rounds):
         kc.reset(); kc.kernel_times(clear=True)
         kc.submit_reads(b, q, o, nreads=n); kc.finalize(); torch.cuda.synchronize()
     kt = {k_: round(v[1], 2) for k_, v in kc.kernel_times().items()}
-    print("context %d: l1 %.2f l2 %.2f count %.2f" % (r, kt.get("kc_l1_reads_kernel", 0), kt.get("kc_l2_split_kernel", 0), kt.get("kc_count_kernel", 0)), flush=True)
+    print("context %d: l1 %.2f l2 %.2f count %.2f" % (r, kt.get("kc_l1_reads_kernel", 0), kt.get("kc_l2_split_kernel", 0) + kt.get("kc_l2_rec6_kernel", 0), kt.get("kc_count_kernel", 0)), flush=True)
     sys.stderr.flush()
     kc.close()

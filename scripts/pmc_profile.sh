@@ -44,6 +44,6 @@ for f in glob.glob("$R/gpurun_out/pmc_grbm/*/*_kernel_trace.csv"):
             agg[k]["effective_clock_GHz"] = agg[k]["GRBM_GUI_ACTIVE"] / 8.0 / sec / 1e9
 json.dump(agg, open("$R/gpurun_out/pmc_summary.json", "w"), indent=1, sort_keys=True)
 for k, v in agg.items():
-    if any(x in k for x in ("l1_reads", "l2_split", "l2_pairs", "count_kernel")):
+    if any(x in k for x in ("l1_reads", "l2_split", "l2_rec6", "count_kernel")):
         print(k[-48:], {a: "%.3g" % b for a, b in sorted(v.items())})
 PY

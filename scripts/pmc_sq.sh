@@ -12,5 +12,5 @@ for d in ['pmc_sq','pmc_sq2']:
         k=r['Kernel_Name'].split('(')[0][-30:]
         agg[k][r['Counter_Name']]+=float(r['Counter_Value'])
     for k,v in agg.items():
-        if any(x in k for x in ['l1_reads','l2_split','count_kernel']): print(k, {a:'%.3g'%b for a,b in sorted(v.items())})
+        if any(x in k for x in ['l1_reads','l2_split','l2_rec6','count_kernel']): print(k, {a:'%.3g'%b for a,b in sorted(v.items())})
 PY

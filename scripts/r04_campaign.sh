@@ -39,7 +39,7 @@ for d in "abcd":
             acc[r["Kernel_Name"].split("(")[0].replace("void ", "")][r["Counter_Name"]] += float(r["Counter_Value"])
         for k, v in acc.items():
             agg[k].update(v)
-json.dump({k: v for k, v in agg.items() if any(x in k for x in ("l1_reads", "l2_split", "count_kernel"))}, open("$O/pmc_k51_30Mreads.json", "w"), indent=1, sort_keys=True)
+json.dump({k: v for k, v in agg.items() if any(x in k for x in ("l1_reads", "l2_split", "l2_rec6", "count_kernel"))}, open("$O/pmc_k51_30Mreads.json", "w"), indent=1, sort_keys=True)
 PY
 echo "pmc k51 done"
 cd $R

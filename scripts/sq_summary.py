@@ -3,7 +3,7 @@ python scripts/sq_summary.py gpurun_out/pmc_sq/runc/N_counter_collection.csv gpu
 Only the FIRST dispatch of each hot kernel after the warm-up is taken for the split kernels (one launch of level 2 and of
 the count kernel is a whole step; level 1's launches of the step are summed)."""
 import csv, sys, collections
-HOT = ("kc_l1_reads16_kernel", "kc_l1_reads_kernel", "kc_l2_split_kernel", "kc_count_kernel")
+HOT = ("kc_l1_reads16_kernel", "kc_l1_reads_kernel", "kc_l2_rec6_kernel", "kc_l2_split_kernel", "kc_count_kernel")
 agg = collections.defaultdict(lambda: collections.defaultdict(float))
 ndisp = collections.defaultdict(set)
 for f in sys.argv[1:]:

@@ -51,7 +51,10 @@ def test_hot_kernels_do_not_spill_vector_registers():
     # the count kernel of compact records: two workgroups per CU need at most 64 registers
     cnt = one("_ZN2kc15kc_count_kernelILi1ELb0ELb1EE")
     assert cnt["vgpr_spill_count"] == 0 and cnt["private_segment_fixed_size"] == 0 and cnt["vgpr_count"] <= 64, cnt
-    # level 2 of short-form compact records: three registers are spilled in the per-BUCKET prologue and epilogue (a pair of
+    # level 2 of the benchmark configuration (six-byte level-1 records, k = 21): nothing spilled
+    l26 = one("_ZN2kc17kc_l2_rec6_kernelILb0ELb0EE")
+    assert l26["vgpr_spill_count"] == 0 and l26["private_segment_fixed_size"] == 0 and l26["vgpr_count"] <= 128, l26
+    # level 2 of the other short-form compact records: three registers are spilled in the per-BUCKET prologue and epilogue (a pair of
     # zeros and the lane id, four times per workgroup and step), none inside the round loop
     l2 = one("_ZN2kc18kc_l2_split_kernelILi1ELb1ELb1ELb0ELb0EE")
     assert l2["vgpr_spill_count"] <= 3 and l2["private_segment_fixed_size"] <= 16 and l2["vgpr_count"] <= 128, l2

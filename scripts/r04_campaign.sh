@@ -9,7 +9,7 @@ python3 bench.py > $O/bench_default.json 2> $O/bench_default.err || exit 1
 echo "bench default done"; tail -c 200 $O/bench_default.json
 bash scripts/profile_bench.sh > $O/profile_bench.txt 2>&1
 cp gpurun_out/prof_bench/*/*_kernel_stats.csv $O/bench_default_kernel_stats.csv 2>/dev/null
-tail -1 gpurun_out/prof_bench.log > $O/bench_default_under_rocprof.json
+grep -h "^{\"metric\"" gpurun_out/prof_bench.log > $O/bench_default_under_rocprof.json
 echo "kernel stats done"
 bash scripts/pmc_profile.sh > $O/pmc_profile.txt 2>&1
 cp gpurun_out/pmc_summary.json $O/pmc_50Mreads.json
@@ -19,7 +19,7 @@ cd /tmp && export TMPDIR=/tmp
 for k in 33 51 55 77; do
   rm -rf $R/gpurun_out/prof_k$k
   rocprofv3 --kernel-trace --stats --output-format csv -d $R/gpurun_out/prof_k$k -- python3 $R/bench.py --k $k --reads 30000000 --steps 3 --warmup 1 --cpu-sample-reads 0 --no-end-to-end > $O/bench_k$k.log 2>&1
-  tail -1 $O/bench_k$k.log > $O/bench_k$k.json
+  grep -h "^{\"metric\"" $O/bench_k$k.log > $O/bench_k$k.json
   cp $R/gpurun_out/prof_k$k/*/*_kernel_stats.csv $O/bench_k${k}_kernel_stats.csv 2>/dev/null
   echo "k=$k done"
 done

@@ -241,7 +241,7 @@ def main():
     def make_counter(buckets):
         return pkg.KmerCounter(k, device=local_rank, rank_me=rank, rank_n=world, max_elems=est_unique, time_kernels=True,
                                max_kmers_buffered=int(nreads * (L - k - 1) * (1.05 if sharded_path else 1.02)) + (1 << 20), tuning=ap_tuning,
-                               shard_buckets=buckets)
+                               shard_buckets=buckets, wire_units=True)
 
     kc = make_counter(flow == "single-pass")
     if flow == "single-pass" and a.shard_flow == "auto":
@@ -282,7 +282,9 @@ def main():
             seg_words = (int(blk * (L - k - 1) / world * 1.1) * kc.rec_nl + 4096) if world > 1 else 1024
             sharded = ShardedKmerAnalysis.single_pass(kc, shard_extract, seg_words, dev)
         else:
-            sharded = ShardedKmerAnalysis(extract, lambda recv, n: kc.insert_records(recv, n), kc.rec_nl, seg, dev, counter=kc)
+            # units of the library's own wire record (kc_wire_unit): four six-byte records per three words at k = 21
+            unit_words, unit_records = kc.wire_unit()
+            sharded = ShardedKmerAnalysis(extract, lambda recv, n: kc.insert_records(recv, n), unit_words, seg // unit_records + 4096, dev, counter=kc)
 
     def step():
         kc.reset()

@@ -78,6 +78,10 @@ typedef struct kc_config {
                                      unmodified MHM2 ranks; slower (k-m+1 m-mer comparisons per k-mer) */
 #define KC_FLAG_SHARD_BUCKETS 4u /* this context will run the single-pass shard flow (kc_shard_*): its regions are sized for 1/rank_n
                                  * of the level-1 buckets holding all of max_elems (see kc_shard_capacity) */
+#define KC_FLAG_WIRE_UNITS 8u /* kc_extract_partition / kc_insert_records exchange UNITS of the library's own wire record where the
+                                 geometry has one (kc_wire_unit: four six-byte records of a mixed k-mer per three words for k = 21;
+                                 one k-mer record otherwise) and the owner of a k-mer is kc_partition_owner, not kc_owner.  All
+                                 shards of an exchange must be created alike. */
 #define KC_FLAG_TIME_KERNELS 1u /* bracket every kernel launch with HIP events on its own stream (kc_get_kernel_times) */
 
 /* Scalars the reference logs (src/kcount/kcount.cpp:94-102,158-160;
@@ -207,6 +211,19 @@ int kc_extract_partition_seq_block(kc_ctx *ctx, const char *seqs, uint64_t len, 
 /* Receiver side: HashTableGPUDriver::insert_supermer/insert_supermer_block
  * (gpu_hash_table.cpp:655-695) for records that arrived from other shards. */
 int kc_insert_records(kc_ctx *ctx, const uint64_t *d_records, uint64_t n);
+
+/* What kc_extract_partition writes and kc_insert_records reads, for contexts created with KC_FLAG_WIRE_UNITS: a unit is
+ * *unit_words words holding *unit_records records; seg_capacity, h_counts and n count UNITS, segment d starts at
+ * d_records + d * seg_capacity * *unit_words.  Where level 1 writes six-byte records (k = 21 with the default geometry) a
+ * unit is three words = four records of six bytes -- the k-mer travels mixed, as level 1 stages it, so the receiver neither
+ * unpacks nor hashes it; a run a sender appends is padded to whole units with marker slots, so units from several senders
+ * can be laid end to end -- and the two extra passes of this flow cost about two thirds of what they cost with k-mer
+ * records.  Otherwise (and without the flag) a unit is one k-mer record of kc_record_longs words.  Units are opaque. */
+int kc_wire_unit(kc_ctx *ctx, int *unit_words, int *unit_records);
+/* The shard kc_extract_partition sends a canonical k-mer to (role of KmerDHT::get_kmer_target_rank, kmer_dht.cpp:192-196):
+ * kc_owner / kc_owner_reference for k-mer records; eight bits of the mixed k-mer for six-byte wire records (bits only
+ * the probe stride of a region table uses, so every shard keeps the whole geometry). */
+int kc_partition_owner(kc_ctx *ctx, const uint64_t *kmer_words, int *owner);
 
 /* ---- the single-pass shard flow: a shard owns level-1 BUCKETS --------------------------------------------
  * Same role as kc_extract_partition + kc_insert_records -- the aggregated supermer exchange of

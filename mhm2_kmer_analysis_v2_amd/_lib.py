@@ -11,6 +11,7 @@ KC_ERR_BAD_BASE = -7
 KC_FLAG_TIME_KERNELS = 1
 KC_FLAG_REFERENCE_OWNER = 2
 KC_FLAG_SHARD_BUCKETS = 4
+KC_FLAG_WIRE_UNITS = 8
 
 
 class KcError(RuntimeError):
@@ -83,6 +84,8 @@ SYMBOLS = {
     "kc_shard_reserve": (C.c_int, [C.c_void_p, C.c_uint64, C.POINTER(C.c_void_p)]),
     "kc_shard_commit": (C.c_int, [C.c_void_p, C.c_void_p, C.c_uint64]),
     "kc_shard_owner": (C.c_int, [C.c_void_p, C.c_void_p, C.POINTER(C.c_int)]),
+    "kc_wire_unit": (C.c_int, [C.c_void_p, C.POINTER(C.c_int), C.POINTER(C.c_int)]),
+    "kc_partition_owner": (C.c_int, [C.c_void_p, C.c_void_p, C.POINTER(C.c_int)]),
     "kc_shard_capacity": (C.c_int, [C.c_void_p, C.POINTER(C.c_uint64)]),
     "kc_build_supermers": (C.c_int, [C.c_void_p, C.c_void_p, C.c_uint64, C.c_int, C.c_void_p, C.c_uint32, C.POINTER(C.c_uint32),
                                       C.POINTER(C.c_uint32), C.c_void_p]),

@@ -20,6 +20,7 @@
 #include "../../include/kcount_mi355.h"
 #include "kc_bucketed.hpp"
 #include "kc_shard.hpp"
+#include "kc_wire6.hpp"
 #include "kc_supermer.hpp"
 #include "kc_ctg.hpp"
 
@@ -39,12 +40,12 @@ static int hip_fail(hipError_t e, const char *what, int line) {
   } while (0)
 
 enum { KT_EXTRACT_INSERT = 0, KT_EXTRACT_BIN, KT_INSERT_RECORDS, KT_FINALIZE, KT_TILE_FIRST, KT_REHASH, KT_L1_READS, KT_L1_RECORDS,
-       KT_L2_SPLIT, KT_COUNT_REGIONS, KT_FALLBACK, KT_SHARD_PACK, KT_L1_READS_UQ, KT_L1_READS16, KT_L2_REC6, KT_COUNT };
+       KT_L2_SPLIT, KT_COUNT_REGIONS, KT_FALLBACK, KT_SHARD_PACK, KT_L1_READS_UQ, KT_L1_READS16, KT_L2_REC6, KT_BIN16, KT_L1_WIRE6, KT_COUNT };
 static const char *const kt_names[KT_COUNT] = {"kc_extract_kernel<insert>", "kc_bin_reads_kernel", "kc_insert_records_kernel",
                                                "kc_finalize_kernel", "kc_tile_first_kernel", "kc_rehash_kernel",
                                                "kc_l1_reads_kernel", "kc_l1_records_kernel", "kc_l2_split_kernel",
                                                "kc_count_kernel", "kc_flagged_to_table_kernel", "kc_shard_pack_kernel",
-                                               "kc_l1_reads_kernel<byte-loaded qualities>", "kc_l1_reads16_kernel", "kc_l2_rec6_kernel"};
+                                               "kc_l1_reads_kernel<byte-loaded qualities>", "kc_l1_reads16_kernel", "kc_l2_rec6_kernel", "kc_bin16_kernel", "kc_l1_wire6_kernel"};
 struct kt_pending {
   hipEvent_t start, stop;
   int kind;
@@ -130,6 +131,7 @@ struct kc_ctx {
   bool inc_on;           // level 2 has begun in instalments (kc_l2_split_kernel<..., INC>): bb.done1 / used2 / cnt2 carry its state
   uint64_t *d_cb, *h_cb;
   bool bk_spilled;       // earlier buffer-fulls of this pass were counted and merged into the global table (bk_spill_pass)
+  bool wire6;            // KC_FLAG_WIRE_UNITS and a geometry of six-byte records: kc_extract_partition / kc_insert_records speak kc_wire6.hpp's units
   bool l1_dropped;       // earlier buffer-fulls of this pass went through level 2 and left level 1 (bk_light_spill): level 2 holds them
   uint64_t l2_held;      // ... that many records (an upper bound)
   uint64_t l2_per_bucket;  // records every bucket's part of the level-2 arena has room for while level 2 runs in instalments
@@ -603,6 +605,7 @@ static void bk_free(kc_ctx *c, bool keep = false) {
   }
   memset(&c->bb, 0, sizeof(c->bb));
   c->bk_ready = false;
+  c->wire6 = false;
   c->bk_bytes = 0;
 }
 
@@ -776,6 +779,9 @@ static int bk_init(kc_ctx *c) {
     static const bool round16 = !(getenv("KC_L1_ROUND16") && getenv("KC_L1_ROUND16")[0] == '0');
     g.rec6 = (c->nl == 1 && g.cp && c->k == 21 && g.k2 - g.la <= 32 && round16) ? 1u : 0u;
   }
+  // the records flow's wire: units of four six-byte records where level 1 writes those (kc_wire6.hpp), k-mer records otherwise
+  c->wire6 = (c->cfg.flags & KC_FLAG_WIRE_UNITS) && g.rec6 && !(c->cfg.flags & KC_FLAG_REFERENCE_OWNER) && c->cfg.rank_n >= 1 &&
+             c->cfg.rank_n <= (int)WIRE6_MAX_SHARDS;
   // one writer per CU, but never so many that a writer's share of the buffer is below a few rounds of records
   g.G = t.writers ? std::min<uint32_t>(t.writers, GMAX)
                   : (uint32_t)std::max<uint64_t>(1, std::min<uint64_t>((uint64_t)std::min<int>(c->num_cus, GMAX), bcap / (4 * 16384)));
@@ -1018,7 +1024,24 @@ static int launch_bin_reads_t(kc_ctx *c, const ExtractArgs &a, uint64_t nsuper) 
   return KC_OK;
 }
 
+template <int FMT>
+static int launch_bin16_t(kc_ctx *c, const ExtractArgs &a, uint64_t nsuper) {
+  auto kern = kc_bin16_kernel<FMT, 21>;
+  int rc = set_dyn_lds(kern, bin16_lds_bytes());
+  if (rc) return rc;
+  const unsigned grid = (unsigned)std::min<uint64_t>((uint64_t)c->num_cus, nsuper);
+  KernelTimer kt(c, KT_BIN16);
+  hipLaunchKernelGGL(kern, dim3(grid), dim3(WGB), bin16_lds_bytes(), c->stream, a, c->gm, nsuper, c->d_ctrs);
+  return KC_OK;
+}
+
 static int launch_bin_reads(kc_ctx *c, const ExtractArgs &a, uint64_t ntiles, int fmt) {
+  if (c->wire6) {  // six-byte wire records (kc_wire6.hpp)
+    if (fmt == FMT_READS) return launch_bin16_t<FMT_READS>(c, a, ntiles);
+    if (fmt == FMT_READS_UQ) return launch_bin16_t<FMT_READS_UQ>(c, a, ntiles);
+    if (fmt == FMT_PACKED) return launch_bin16_t<FMT_PACKED>(c, a, ntiles);
+    return launch_bin16_t<FMT_SEQBLOCK>(c, a, ntiles);
+  }
   if (fmt == FMT_READS) {
     switch (c->nl) {
       case 1: return launch_bin_reads_t<1, FMT_READS>(c, a, ntiles);
@@ -1074,6 +1097,21 @@ static int launch_l1_records_t(kc_ctx *c, const uint64_t *recs, uint64_t n) {
   KernelTimer kt(c, KT_L1_RECORDS);
   hipLaunchKernelGGL(kern, dim3(grid), dim3(WGB), lds_l1_records<NL>(), c->stream, recs, n, c->gm, c->bb, c->bk_rot, c->d_ctrs, c->d_cb);
   c->bk_rot = (uint32_t)((c->bk_rot + (n + per_round - 1) / per_round) % c->gm.G);
+  return KC_OK;
+}
+
+// level 1 from wire units (kc_wire6.hpp): nslots six-byte slots at `recs`
+static int launch_l1_wire6(kc_ctx *c, const uint8_t *recs, uint64_t nslots) {
+  c->gm.own_lo = 0;
+  c->gm.own_hi = PMAX;
+  const uint64_t per_round = (uint64_t)WGB * R16;
+  const uint64_t rounds = (nslots + per_round - 1) / per_round;
+  const unsigned grid = (unsigned)std::min<uint64_t>(c->gm.G, rounds);
+  int rc = set_dyn_lds(kc_l1_wire6_kernel, l1r16_lds_bytes());
+  if (rc) return rc;
+  KernelTimer kt(c, KT_L1_WIRE6);
+  hipLaunchKernelGGL(kc_l1_wire6_kernel, dim3(grid), dim3(WGB), l1r16_lds_bytes(), c->stream, recs, nslots, c->gm, c->bb, c->bk_rot, c->d_ctrs, c->d_cb);
+  c->bk_rot = (uint32_t)((c->bk_rot + rounds) % c->gm.G);
   return KC_OK;
 }
 
@@ -1787,48 +1825,58 @@ extern "C" int kc_submit_packed_supermers(kc_ctx *c, const uint8_t *packed, uint
   return kc_submit_seq_block(c, (const char *)c->d_sm_bytes, len * 2, 1);
 }
 
+// the two ends of a kc_extract_partition call.  With KC_FLAG_WIRE_UNITS the geometry decides what a unit is, so it is
+// chosen now (bk_init); the counters then count slots of six bytes, four to a unit.
+static int bin_begin(kc_ctx *c) {
+  if ((c->cfg.flags & KC_FLAG_WIRE_UNITS) && bk_active(c)) {
+    int rc = bk_init(c);
+    if (rc) return rc;
+  }
+  HIPCHK(hipMemsetAsync(c->d_ctrs + CTR_OVERFLOW, 0, (1 + 64) * 8, c->stream));
+  return KC_OK;
+}
+static int bin_end(kc_ctx *c, uint64_t seg_capacity, uint64_t *h_counts) {
+  int rc = sync_ctrs(c);
+  if (rc) return rc;
+  const uint64_t per_unit = c->wire6 ? WIRE6_UNIT_RECORDS : 1;
+  for (int d = 0; d < c->cfg.rank_n; d++) h_counts[d] = c->h_ctrs[CTR_BIN0 + d] / per_unit;
+  if (c->h_ctrs[CTR_BAD_BASE]) return KC_ERR_BAD_BASE;
+  if (c->h_ctrs[CTR_OVERFLOW]) {
+    snprintf(g_last_error, sizeof(g_last_error), "a shard segment is too small: raise seg_capacity (%llu %s)", (unsigned long long)seg_capacity,
+             c->wire6 ? "units of four records" : "records");
+    return KC_ERR_CAPACITY;
+  }
+  return KC_OK;
+}
+
 extern "C" int kc_extract_partition(kc_ctx *c, const uint8_t *bases, const uint8_t *quals, const uint64_t *offsets, uint64_t nreads,
                                     int on_device, uint64_t *d_records, uint64_t seg_capacity, uint64_t *h_counts) {
   if (!c || !h_counts || (nreads && !d_records)) return KC_ERR_INVALID_ARG;
   HIPCHK(hipSetDevice(c->cfg.device));
-  HIPCHK(hipMemsetAsync(c->d_ctrs + CTR_OVERFLOW, 0, (1 + 64) * 8, c->stream));
-  int rc = submit_reads_impl(c, bases, quals, offsets, nreads, on_device, MODE_BIN, d_records, seg_capacity);
+  int rc = bin_begin(c);
   if (rc) return rc;
-  rc = sync_ctrs(c);
+  rc = submit_reads_impl(c, bases, quals, offsets, nreads, on_device, MODE_BIN, d_records, seg_capacity);
   if (rc) return rc;
-  for (int d = 0; d < c->cfg.rank_n; d++) h_counts[d] = c->h_ctrs[CTR_BIN0 + d];
-  if (c->h_ctrs[CTR_BAD_BASE]) return KC_ERR_BAD_BASE;
-  if (c->h_ctrs[CTR_OVERFLOW]) {
-    snprintf(g_last_error, sizeof(g_last_error), "a shard segment is too small: raise seg_capacity (%llu records)", (unsigned long long)seg_capacity);
-    return KC_ERR_CAPACITY;
-  }
-  return KC_OK;
+  return bin_end(c, seg_capacity, h_counts);
 }
 
 extern "C" int kc_extract_partition_seq_block(kc_ctx *c, const char *seqs, uint64_t len, int on_device, uint64_t *d_records,
                                               uint64_t seg_capacity, uint64_t *h_counts) {
   if (!c || !h_counts || (len && (!seqs || !d_records))) return KC_ERR_INVALID_ARG;
   HIPCHK(hipSetDevice(c->cfg.device));
-  HIPCHK(hipMemsetAsync(c->d_ctrs + CTR_OVERFLOW, 0, (1 + 64) * 8, c->stream));
+  int rc = bin_begin(c);
+  if (rc) return rc;
   const uint8_t *d = (const uint8_t *)seqs;
   if (len && !on_device) {
-    int rc = ensure_stage(c, (size_t)len, 0, false);
+    rc = ensure_stage(c, (size_t)len, 0, false);
     if (rc) return rc;
     HIPCHK(hipStreamSynchronize(c->stream));
     HIPCHK(hipMemcpyAsync(c->d_stage_bases, seqs, len, hipMemcpyHostToDevice, c->stream));
     d = c->d_stage_bases;
   }
-  int rc = run_extract_device(c, d, nullptr, nullptr, 0, len, MODE_BIN, FMT_SEQBLOCK, d_records, seg_capacity);
+  rc = run_extract_device(c, d, nullptr, nullptr, 0, len, MODE_BIN, FMT_SEQBLOCK, d_records, seg_capacity);
   if (rc) return rc;
-  rc = sync_ctrs(c);
-  if (rc) return rc;
-  for (int t = 0; t < c->cfg.rank_n; t++) h_counts[t] = c->h_ctrs[CTR_BIN0 + t];
-  if (c->h_ctrs[CTR_BAD_BASE]) return KC_ERR_BAD_BASE;
-  if (c->h_ctrs[CTR_OVERFLOW]) {
-    snprintf(g_last_error, sizeof(g_last_error), "a shard segment is too small: raise seg_capacity (%llu records)", (unsigned long long)seg_capacity);
-    return KC_ERR_CAPACITY;
-  }
-  return KC_OK;
+  return bin_end(c, seg_capacity, h_counts);
 }
 
 template <int NL>
@@ -1866,10 +1914,15 @@ extern "C" int kc_insert_records(kc_ctx *c, const uint64_t *d_records, uint64_t 
   HIPCHK(hipSetDevice(c->cfg.device));
   if (!n) return KC_OK;
   c->started = true;
+  // wire units (KC_FLAG_WIRE_UNITS with a geometry of six-byte records): n counts units of four slots, markers among them
   if (bk_active(c)) {
     int rc = bk_init(c);
     if (rc) return rc;
-    rc = sync_ctrs(c);
+  }
+  const bool w6 = c->wire6;
+  if (w6) n *= WIRE6_UNIT_RECORDS;  // slots from here on
+  if (bk_active(c)) {
+    int rc = sync_ctrs(c);
     if (rc) return rc;
     const uint64_t buffered = c->h_ctrs[CTR_EXPECT] - c->expect_base;
     bool fits = buffered + n <= c->bk_capacity;
@@ -1892,12 +1945,24 @@ extern "C" int kc_insert_records(kc_ctx *c, const uint64_t *d_records, uint64_t 
         uint64_t room = 0;
         rc = bk_ovf1_room(c, n - done, &room);
         if (rc) return rc;
-        const uint64_t m = std::min<uint64_t>(n - done, room);
+        uint64_t m = std::min<uint64_t>(n - done, room);
         if (!m) {
           snprintf(g_last_error, sizeof(g_last_error), "overflow list has no room: raise ovf_capacity");
           return KC_ERR_CAPACITY;
         }
         c->ovf1_ub += m;
+        if (w6) {
+          if (m < n - done) m &= ~(uint64_t)(WIRE6_UNIT_RECORDS - 1);  // pieces of whole units
+          if (!m) {
+            snprintf(g_last_error, sizeof(g_last_error), "overflow list has no room: raise ovf_capacity");
+            return KC_ERR_CAPACITY;
+          }
+          rc = launch_l1_wire6(c, reinterpret_cast<const uint8_t *>(d_records) + done * 6, m);
+          if (rc) return rc;
+          HIPCHK(hipGetLastError());
+          done += m;
+          continue;
+        }
         const uint64_t *p = d_records + done * c->nl;
         switch (c->nl) {
           case 1: rc = launch_l1_records_t<1>(c, p, m); break;
@@ -1912,7 +1977,54 @@ extern "C" int kc_insert_records(kc_ctx *c, const uint64_t *d_records, uint64_t 
       return KC_OK;
     }
   }
+  if (w6) {  // the context has left the bucketed path: back to k-mer records for the global table
+    uint64_t *tmp = nullptr;
+    HIPCHK(hipMalloc((void **)&tmp, (n + 1) * 8));
+    int rc = KC_OK;
+    unsigned long long h_n = 0;
+    if (hipMemsetAsync(tmp + n, 0, 8, c->stream) != hipSuccess) rc = KC_ERR_HIP;
+    if (!rc) {
+      hipLaunchKernelGGL(kc_wire6_expand_kernel, dim3((unsigned)std::min<uint64_t>((n + TPB - 1) / TPB, 256 * 32)), dim3(TPB), 0, c->stream,
+                         reinterpret_cast<const uint8_t *>(d_records), n, c->gm, tmp, (unsigned long long *)(tmp + n));
+      c->num_gpu_calls++;
+      if (hipMemcpyAsync(&h_n, tmp + n, 8, hipMemcpyDeviceToHost, c->stream) != hipSuccess || hipStreamSynchronize(c->stream) != hipSuccess) rc = KC_ERR_HIP;
+    }
+    if (!rc && h_n) rc = table_insert_records(c, tmp, h_n, 1u);
+    if (hipStreamSynchronize(c->stream) != hipSuccess && !rc) rc = KC_ERR_HIP;
+    (void)hipFree(tmp);
+    return rc;
+  }
   return table_insert_records(c, d_records, n, 1u);
+}
+
+extern "C" int kc_wire_unit(kc_ctx *c, int *unit_words, int *unit_records) {
+  if (!c || !unit_words || !unit_records) return KC_ERR_INVALID_ARG;
+  HIPCHK(hipSetDevice(c->cfg.device));
+  if ((c->cfg.flags & KC_FLAG_WIRE_UNITS) && bk_active(c)) {
+    int rc = bk_init(c);  // the geometry decides
+    if (rc) return rc;
+  }
+  *unit_words = c->wire6 ? (int)WIRE6_UNIT_WORDS : c->nl;
+  *unit_records = c->wire6 ? (int)WIRE6_UNIT_RECORDS : 1;
+  return KC_OK;
+}
+
+extern "C" int kc_partition_owner(kc_ctx *c, const uint64_t *kmer, int *owner) {
+  if (!c || !kmer || !owner) return KC_ERR_INVALID_ARG;
+  HIPCHK(hipSetDevice(c->cfg.device));
+  if ((c->cfg.flags & KC_FLAG_WIRE_UNITS) && bk_active(c)) {
+    int rc = bk_init(c);
+    if (rc) return rc;
+  }
+  if (c->wire6) {
+    const uint64_t mix = kc_feistel_fwd(kmer[0] >> (64u - c->gm.k2), c->k);
+    *owner = (int)wire6_owner((uint32_t)mix, (uint32_t)c->cfg.rank_n);
+    return KC_OK;
+  }
+  const int o = (c->cfg.flags & KC_FLAG_REFERENCE_OWNER) ? kc_owner_reference(kmer, c->k, c->cfg.rank_n) : kc_owner(kmer, c->k, c->cfg.rank_n);
+  if (o < 0) return o;
+  *owner = o;
+  return KC_OK;
 }
 
 // ---- shard flow: ownership by level-1 bucket (kernels and the wire format in kc_shard.hpp) -------------------

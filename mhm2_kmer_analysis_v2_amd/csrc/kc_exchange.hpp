@@ -122,7 +122,8 @@ class ShardExchange {
 
  public:
   // ctx: this rank's context (created with the same rank_me / rank_n as `comm`, and -- BUCKETS -- the same sizes and
-  // tuning on every rank); num_longs: kc_record_longs(k); seg_capacity: what one block may send to one shard, in WORDS
+  // tuning on every rank); num_longs: kc_record_longs(k) -- for RECORDS with contexts created with KC_FLAG_WIRE_UNITS the
+  // words of a unit (kc_wire_unit), and seg_capacity in units --; seg_capacity: what one block may send to one shard, in WORDS
   // for BUCKETS (a block of R reads of length L needs about R * (L - k - 1) / rank_n * num_longs * 1.1 + 1024), in
   // RECORDS for RECORDS (R * (L - k - 1) / rank_n * 1.25); compute_stream: the stream the context's kernels should run
   // on, NULL = a stream of this object's own.

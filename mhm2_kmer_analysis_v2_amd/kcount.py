@@ -66,10 +66,10 @@ class KmerCounter:
     """One shard (one GPU) of the k-mer analysis stage."""
 
     def __init__(self, kmer_len, qual_offset=33, dmin_thres=2, device=0, rank_me=0, rank_n=1, max_elems=0, time_kernels=False,
-                 max_kmers_buffered=0, tuning=None, reference_owner=False, shard_buckets=False):
+                 max_kmers_buffered=0, tuning=None, reference_owner=False, shard_buckets=False, wire_units=False):
         L = lib()
         cfg = kc_config(kmer_len=kmer_len, qual_offset=qual_offset, dmin_thres=dmin_thres, device=device, rank_me=rank_me,
-                        rank_n=rank_n, max_elems=max_elems, flags=(_lib.KC_FLAG_TIME_KERNELS if time_kernels else 0) | (_lib.KC_FLAG_REFERENCE_OWNER if reference_owner else 0) | (_lib.KC_FLAG_SHARD_BUCKETS if shard_buckets else 0),
+                        rank_n=rank_n, max_elems=max_elems, flags=(_lib.KC_FLAG_TIME_KERNELS if time_kernels else 0) | (_lib.KC_FLAG_REFERENCE_OWNER if reference_owner else 0) | (_lib.KC_FLAG_SHARD_BUCKETS if shard_buckets else 0) | (_lib.KC_FLAG_WIRE_UNITS if wire_units else 0),
                         reserved=0,
                         max_kmers_buffered=max_kmers_buffered)
         st = C.c_int(0)
@@ -147,8 +147,22 @@ class KmerCounter:
         n = len(seqs) if length is None else length
         check(lib().kc_submit_seq_block(self._h, p, n, 1 if dev else 0), "kc_submit_seq_block")
 
+    def wire_unit(self):
+        """(words, records) of one unit of kc_extract_partition / kc_insert_records: (kc_record_longs, 1) for k-mer records,
+        (3, 4) where a context created with wire_units=True exchanges six-byte records (kc_wire_unit)."""
+        w, r = C.c_int(0), C.c_int(0)
+        check(lib().kc_wire_unit(self._h, C.byref(w), C.byref(r)), "kc_wire_unit")
+        return w.value, r.value
+
+    def partition_owner(self, kmer_words):
+        """the shard kc_extract_partition sends this canonical k-mer to (kc_partition_owner)"""
+        w = np.ascontiguousarray(kmer_words, dtype=np.uint64)
+        o = C.c_int(-1)
+        check(lib().kc_partition_owner(self._h, w.ctypes.data, C.byref(o)), "kc_partition_owner")
+        return o.value
+
     def extract_partition(self, bases, quals, offsets, records, seg_capacity, nreads=None):
-        """records: device buffer of rank_n*seg_capacity*num_longs u64.  Returns per-shard counts."""
+        """records: device buffer of rank_n*seg_capacity*unit_words u64 (wire_unit()).  Returns per-shard counts of units."""
         pb, dev = _ptr(bases)
         pq, _ = _ptr(quals)
         po, _ = _ptr(offsets)

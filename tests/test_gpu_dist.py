@@ -25,7 +25,7 @@ def nccl_world1():
     dist.destroy_process_group()
 
 
-@pytest.mark.parametrize("flow", ["records", "single-pass"])
+@pytest.mark.parametrize("flow", ["records", "records-wire-units", "single-pass"])
 @pytest.mark.parametrize("k,tuning", [(21, dict(p1=1024, p2=1024)), (51, None)], ids=["k21-compact", "k51"])
 def test_sharded_analysis_over_nccl(nccl_world1, k, tuning, flow):
     import torch
@@ -43,7 +43,7 @@ def test_sharded_analysis_over_nccl(nccl_world1, k, tuning, flow):
     db = torch.from_numpy(b).to(dev)
     dq = torch.from_numpy(q).to(dev)
     do = torch.from_numpy(offs.astype(np.int64)).to(dev)
-    with pkg.KmerCounter(k, rank_me=0, rank_n=1, tuning=tuning) as kc:  # created on its own stream: the class must move it
+    with pkg.KmerCounter(k, rank_me=0, rank_n=1, tuning=tuning, wire_units=flow == "records-wire-units") as kc:  # created on its own stream: the class must move it
         def extract(block, send, seg_cap):
             r0, r1 = block
             o0 = int(offs[r0])
@@ -54,8 +54,14 @@ def test_sharded_analysis_over_nccl(nccl_world1, k, tuning, flow):
             o0 = int(offs[r0])
             return kc.shard_extract(db[o0:], dq[o0:], do[r0:r1 + 1] - do[r0], send, seg_words, nreads=r1 - r0)
 
+        units = None
         if flow == "records":
             sh = ShardedKmerAnalysis(extract, lambda recv, n: kc.insert_records(recv, n), nl, 600 * 150, dev, counter=kc)
+        elif flow == "records-wire-units":  # units of four six-byte records at k = 21 (kc_wire_unit), k-mer records at k = 51
+            uw, ur = kc.wire_unit()
+            assert (uw, ur) == ((3, 4) if k == 21 else (nl, 1))
+            units = ur
+            sh = ShardedKmerAnalysis(extract, lambda recv, n: kc.insert_records(recv, n), uw, 600 * 150 // ur + 4096, dev, counter=kc)
         else:  # kc_shard_extract / kc_shard_reserve / kc_shard_commit: with one member nothing leaves the shard
             sh = ShardedKmerAnalysis.single_pass(kc, shard_extract, 600 * 150 * nl + 2048, dev)
         for r0 in range(0, 4000, 600):  # seven blocks: both buffers are reused several times
@@ -63,7 +69,10 @@ def test_sharded_analysis_over_nccl(nccl_world1, k, tuning, flow):
         sh.finish()
         got = kc.sorted_results()
         st = kc.stats()
-    assert sh.sent == sh.received == (wst["kmers_inserted"] if flow == "records" else 0)
+    if units is None:
+        assert sh.sent == sh.received == (wst["kmers_inserted"] if flow == "records" else 0)
+    else:  # whole units: the records and a few marker slots
+        assert sh.sent == sh.received and wst["kmers_inserted"] <= sh.sent * units <= wst["kmers_inserted"] + 64 * units
     assert st["kmers_inserted"] == wst["kmers_inserted"]
     for g, w in zip(got, want):
         assert g.shape == w.shape and (g == w).all()

@@ -1,0 +1,176 @@
+"""The records flow with the library's own wire record (KC_FLAG_WIRE_UNITS, csrc/kc_wire6.hpp): kc_extract_partition writes
+units of four six-byte records of the MIXED k-mer, kc_insert_records takes them as they are.  Several shards live on the
+one GPU; the union of their results must be the oracle's set, bit for bit, and every k-mer must sit in the shard
+kc_partition_owner names."""
+import numpy as np
+import pytest
+
+import mhm2_kmer_analysis_v2_amd as pkg
+from test_gpu_parity import PATHS, arrays, assert_same, oracle_run, random_reads
+
+pytestmark = pytest.mark.gpu
+
+SHORT = PATHS["compact-short"]  # 1024 level-1 buckets: six-byte records at k = 21
+
+
+def union(parts):
+    keys = np.concatenate([p[0] for p in parts])
+    order = np.lexsort([keys[:, j] for j in range(keys.shape[1] - 1, -1, -1)])
+    return tuple(np.concatenate([p[i] for p in parts])[order] for i in range(4))
+
+
+def run_flow(reads, quals, k, R, tuning, blocks=3, wire_units=True, **kw):
+    import torch
+    shards = [pkg.KmerCounter(k, rank_me=r, rank_n=R, tuning=tuning, wire_units=wire_units, time_kernels=True, **kw) for r in range(R)]
+    uw, ur = shards[0].wire_unit()
+    worst = sum(max(0, len(r) - k - 1) for r in reads)
+    seg = worst // ur + 8 * 1024  # units: everything to one shard, and a padded run per workgroup round and owner
+    recs = torch.zeros(R * seg * uw, dtype=torch.int64, device="cuda")
+    per = (len(reads) + blocks - 1) // blocks
+    shipped = 0
+    for part in range(blocks):
+        sl = slice(part * per, min(len(reads), (part + 1) * per))
+        if sl.start >= sl.stop:
+            continue
+        bb, qq, oo = arrays(reads[sl], quals[sl])
+        sender = shards[part % R]
+        counts = sender.extract_partition(bb, qq, oo, recs, seg)
+        n_here = sum(max(0, len(r) - k - 1) for r in reads[sl])
+        assert n_here <= int(counts.sum()) * ur <= n_here + 2048 * ur  # whole units: a few marker slots per run
+        shipped += int(counts.sum())
+        for d in range(R):
+            shards[d].insert_records(recs[d * seg * uw:], int(counts[d]))
+            shards[d].flush()
+    return shards, (uw, ur), shipped
+
+
+@pytest.mark.parametrize("R", [1, 2, 3, 8])
+def test_wire_units_flow_matches_the_oracle(R):
+    k = 21
+    rng = np.random.default_rng(700 + R)
+    reads, quals = random_reads(rng, 1500, min_len=30, max_len=150, genome_len=4000)
+    b, q, offs = arrays(reads, quals)
+    want, _, wst = oracle_run(b, q, offs, k)
+    shards, (uw, ur), _ = run_flow(reads, quals, k, R, SHORT)
+    assert (uw, ur) == (3, 4)
+    parts = [s.sorted_results() for s in shards]
+    assert_same(union(parts), want)
+    assert sum(s.stats()["kmers_inserted"] for s in shards) == wst["kmers_inserted"]
+    for r, (s, p) in enumerate(zip(shards, parts)):
+        for i in range(0, len(p[1]), 29):
+            assert s.partition_owner(p[0][i]) == r
+        kt = s.kernel_times()
+        assert "kc_bin_reads_kernel" not in kt and "kc_l1_records_kernel" not in kt
+        if len(p[1]):
+            assert kt["kc_l1_wire6_kernel"][0] >= 1
+    if R > 1:  # the owner bits spread the k-mers over the shards
+        sizes = [len(p[1]) for p in parts]
+        assert min(sizes) > 0.5 * max(sizes)
+    for s in shards:
+        s.close()
+
+
+def test_wire_units_default_geometry_and_packed_reads_and_seq_block():
+    """the benchmark's geometry (default tuning); the sender reads the seq-block format as well"""
+    import torch
+    k, R = 21, 2
+    rng = np.random.default_rng(77)
+    reads, quals = random_reads(rng, 1200, min_len=25, max_len=150, genome_len=3000)
+    b, q, offs = arrays(reads, quals)
+    want, _, _ = oracle_run(b, q, offs, k)
+    shards, _, _ = run_flow(reads, quals, k, R, None, max_kmers_buffered=1 << 22)
+    assert_same(union([s.sorted_results() for s in shards]), want)
+    for s in shards:
+        s.close()
+    # seq block: case-masked, '_'-joined
+    block = "_".join("".join(c if ord(qc) - 33 >= 20 else c.lower() for c, qc in zip(r, ql)) for r, ql in zip(reads, quals)) + "_"
+    shards = [pkg.KmerCounter(k, rank_me=r, rank_n=R, wire_units=True, max_kmers_buffered=1 << 22) for r in range(R)]
+    uw, ur = shards[0].wire_unit()
+    seg = len(block) // ur + 8 * 1024
+    recs = torch.zeros(R * seg * uw, dtype=torch.int64, device="cuda")
+    counts = np.zeros(R, dtype=np.uint64)
+    blk = np.frombuffer(block.encode(), dtype=np.uint8)
+    from mhm2_kmer_analysis_v2_amd.kcount import check
+    check(pkg.lib().kc_extract_partition_seq_block(shards[0]._h, blk.ctypes.data, len(blk), 0, recs.data_ptr(), seg, counts.ctypes.data),
+              "kc_extract_partition_seq_block")
+    for d in range(R):
+        shards[d].insert_records(recs[d * seg * uw:], int(counts[d]))
+    assert_same(union([s.sorted_results() for s in shards]), want)
+    for s in shards:
+        s.close()
+
+
+def test_without_a_six_byte_geometry_the_flag_changes_nothing():
+    """longer k, or a geometry whose level 1 writes 8-byte records: a unit is one k-mer record, the owner is kc_owner's"""
+    for k, tuning in ((21, PATHS["compact"]), (33, None), (51, None)):
+        rng = np.random.default_rng(900 + k)
+        reads, quals = random_reads(rng, 600, min_len=40, max_len=150, genome_len=2000)
+        b, q, offs = arrays(reads, quals)
+        want, _, _ = oracle_run(b, q, offs, k)
+        shards, (uw, ur), _ = run_flow(reads, quals, k, 2, tuning)
+        assert (uw, ur) == (pkg.lib().kc_record_longs(k), 1)
+        parts = [s.sorted_results() for s in shards]
+        assert_same(union(parts), want)
+        L = pkg.lib()
+        for r, (s, p) in enumerate(zip(shards, parts)):
+            for i in range(0, len(p[1]), 41):
+                kw = np.ascontiguousarray(p[0][i])
+                assert s.partition_owner(kw) == r == L.kc_owner(kw.ctypes.data, k, 2)
+        for s in shards:
+            s.close()
+
+
+def test_wire_units_segment_too_small_is_reported():
+    import torch
+    k, R = 21, 2
+    rng = np.random.default_rng(5)
+    reads, quals = random_reads(rng, 400, min_len=60, max_len=150, genome_len=2000)
+    b, q, offs = arrays(reads, quals)
+    with pkg.KmerCounter(k, rank_me=0, rank_n=R, tuning=SHORT, wire_units=True) as kc:
+        recs = torch.zeros(R * 16 * 3, dtype=torch.int64, device="cuda")
+        with pytest.raises(pkg.KcError) as e:
+            kc.extract_partition(b, q, offs, recs, 16)
+        assert e.value.status == -6
+
+
+def test_wire_units_through_a_buffer_smaller_than_the_input_and_into_the_table():
+    """the receiver's buffer fills up: compact records hand level 1 on to level 2 (bk_light_spill); a block larger than the
+    whole buffer sends the context to the global table, which takes the units expanded back to k-mer records"""
+    k, R = 21, 2
+    rng = np.random.default_rng(31)
+    reads, quals = random_reads(rng, 3000, min_len=80, max_len=150, genome_len=6000)
+    b, q, offs = arrays(reads, quals)
+    want, _, _ = oracle_run(b, q, offs, k)
+    total = sum(max(0, len(r) - k - 1) for r in reads)
+    # several blocks, each within the buffer, all of them not: the light way
+    shards, _, _ = run_flow(reads, quals, k, R, SHORT, blocks=6, max_kmers_buffered=total // R // 3)
+    assert_same(union([s.sorted_results() for s in shards]), want)
+    for s in shards:
+        s.close()
+    # one block, larger than the buffer: the table path
+    shards, _, _ = run_flow(reads, quals, k, R, SHORT, blocks=1, max_kmers_buffered=total // R // 4)
+    assert_same(union([s.sorted_results() for s in shards]), want)
+    assert any("kc_insert_records_kernel" in s.kernel_times() for s in shards)
+    for s in shards:
+        s.close()
+
+
+def test_records_that_look_like_marker_slots_are_kept():
+    """every base below the quality cutoff: both extensions of every k-mer are missing, and a missing extension keeps its
+    base in the code's low bits -- in the last bucket such a record would carry the marker's sixteen bits (0xFFFF) if the
+    sender did not keep it off that value"""
+    k, R = 21, 2
+    rng = np.random.default_rng(123)
+    reads, _ = random_reads(rng, 2500, min_len=100, max_len=150, genome_len=200000)
+    quals = ["#" * len(r) for r in reads]
+    b, q, offs = arrays(reads, quals)
+    want, _, wst = oracle_run(b, q, offs, k)
+    shards, _, _ = run_flow(reads, quals, k, R, SHORT, blocks=2)
+    import numpy as np_
+    tables = [s.dump_table() for s in shards]
+    assert sum(s.stats()["kmers_inserted"] for s in shards) == wst["kmers_inserted"]
+    assert sum(len(t[1]) for t in tables) == wst["unique"]
+    assert sum(int(t[1].astype(np_.uint64).sum()) for t in tables) == wst["kmers_inserted"]
+    assert_same(union([s.sorted_results() for s in shards]), want)
+    for s in shards:
+        s.close()

@@ -39,7 +39,7 @@ for c in range(cases):
     elif tuning == "wide":
         t = dict(mode=2, p1=1 << min(la, 8), p2=1 << min(lb, 8))
     occ = sum(max(0, len(r) - k - 1) for r in reads)
-    flow = rng.choice(["plain", "plain", "small-buffer", "shards"])
+    flow = rng.choice(["plain", "plain", "small-buffer", "shards", "records"])
     if flow == "small-buffer" and t is not None:
         t["ovf_capacity"] = 1 << 20  # (the lists of a tiny buffer would not hold one tile)
     try:
@@ -65,6 +65,36 @@ for c in range(cases):
                             dst.copy_(segs[d * seg_words:d * seg_words + w])
                             torch.cuda.synchronize()
                             shards[d].shard_commit(dst, w)
+            parts = [sh.sorted_results() for sh in shards]
+            for sh in shards:
+                sh.close()
+            keys = np.concatenate([p[0] for p in parts])
+            order = np.lexsort([keys[:, j] for j in range(keys.shape[1] - 1, -1, -1)])
+            got = tuple(np.concatenate([p[i] for p in parts])[order] for i in range(4))
+        elif flow == "records":  # kc_extract_partition / kc_insert_records, k-mer records or wire units (csrc/kc_wire6.hpp)
+            R = int(rng.integers(1, 6))
+            wu = bool(rng.integers(0, 2))
+            if wu and k == 21 and rng.integers(0, 2):
+                t = dict(writers=int(rng.integers(1, 9)), p1=1024, p2=1 << int(rng.integers(6, 11)), slots=int(rng.choice([256, 1024, 2048])))  # six-byte records
+            small = bool(rng.integers(0, 2))
+            cap = max(40000, int(occ / R * 0.5)) if small else (1 << 22) * scale
+            if small and t is not None:
+                t["ovf_capacity"] = 1 << 20
+            shards = [pkg.KmerCounter(k, rank_me=r, rank_n=R, max_kmers_buffered=cap, tuning=t, wire_units=wu) for r in range(R)]
+            uw, ur = shards[0].wire_unit()
+            flow = "records(%d shards, unit %d words / %d records%s)" % (R, uw, ur, ", small buffer" if small else "")
+            nb = int(rng.integers(2, 7))
+            seg = occ // ur + 8192
+            recs = torch.zeros(R * seg * uw, dtype=torch.int64, device="cuda")
+            for piece in range(nb):
+                part = list(range(piece * nreads // nb, (piece + 1) * nreads // nb))
+                if not part:
+                    continue
+                bb, qq, oo = O.reads_to_arrays([reads[i] for i in part], [quals[i] for i in part])
+                counts = shards[piece % R].extract_partition(bb, qq, oo, recs, seg)
+                for d in range(R):
+                    shards[d].insert_records(recs[d * seg * uw:], int(counts[d]))
+                    shards[d].flush()
             parts = [sh.sorted_results() for sh in shards]
             for sh in shards:
                 sh.close()

@@ -1,5 +1,6 @@
 """Randomised parity sweep on the GPU against the oracle: random k, geometry, read shapes.
-python scripts/stress_parity.py [cases] [seed] [scale]"""
+python scripts/stress_parity.py [cases] [seed] [scale]
+KC_STRESS_KS=21,51 restricts the k, KC_STRESS_FLOW=records the flow (plain, small-buffer, shards, records)."""
 import os, sys
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 sys.path.insert(0, os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "tests"))
@@ -14,6 +15,8 @@ seed = int(sys.argv[2]) if len(sys.argv) > 2 else 1
 scale = int(sys.argv[3]) if len(sys.argv) > 3 else 1  # multiplies the number of reads and the genome length
 rng = np.random.default_rng(seed)
 KS = [11, 13, 15, 17, 19, 21, 23, 25, 27, 29, 30, 31, 33, 47, 51, 61, 62, 63, 65, 77, 93, 95]
+if os.environ.get("KC_STRESS_KS"):
+    KS = [int(x) for x in os.environ["KC_STRESS_KS"].split(",")]
 bad = 0
 for c in range(cases):
     k = int(rng.choice(KS))
@@ -40,6 +43,7 @@ for c in range(cases):
         t = dict(mode=2, p1=1 << min(la, 8), p2=1 << min(lb, 8))
     occ = sum(max(0, len(r) - k - 1) for r in reads)
     flow = rng.choice(["plain", "plain", "small-buffer", "shards", "records"])
+    flow = os.environ.get("KC_STRESS_FLOW", flow)
     if flow == "small-buffer" and t is not None:
         t["ovf_capacity"] = 1 << 20  # (the lists of a tiny buffer would not hold one tile)
     try:

@@ -283,8 +283,12 @@ def main():
             sharded = ShardedKmerAnalysis.single_pass(kc, shard_extract, seg_words, dev)
         else:
             # units of the library's own wire record (kc_wire_unit): four six-byte records per three words at k = 21
-            unit_words, unit_records = kc.wire_unit()
-            sharded = ShardedKmerAnalysis(extract, lambda recv, n: kc.insert_records(recv, n), unit_words, seg // unit_records + 4096, dev, counter=kc)
+            # (and a destination's records in `pieces` pieces by the top bits of their level-1 bucket: the receiver's level 1
+            # then appends long runs to few buckets at a time)
+            unit_words, unit_records, pieces = kc.wire_unit()
+            sharded = ShardedKmerAnalysis(extract, lambda recv, n: kc.insert_records(recv, n), unit_words,
+                                          int(seg / unit_records / pieces * 1.2) + 4096, dev, counter=kc, pieces=pieces,
+                                          insert_pieces=kc.insert_record_pieces)
 
     def step():
         kc.reset()

@@ -213,13 +213,23 @@ int kc_extract_partition_seq_block(kc_ctx *ctx, const char *seqs, uint64_t len, 
 int kc_insert_records(kc_ctx *ctx, const uint64_t *d_records, uint64_t n);
 
 /* What kc_extract_partition writes and kc_insert_records reads, for contexts created with KC_FLAG_WIRE_UNITS: a unit is
- * *unit_words words holding *unit_records records; seg_capacity, h_counts and n count UNITS, segment d starts at
- * d_records + d * seg_capacity * *unit_words.  Where level 1 writes six-byte records (k = 21 with the default geometry) a
- * unit is three words = four records of six bytes -- the k-mer travels mixed, as level 1 stages it, so the receiver neither
- * unpacks nor hashes it; a run a sender appends is padded to whole units with marker slots, so units from several senders
- * can be laid end to end -- and the two extra passes of this flow cost about two thirds of what they cost with k-mer
- * records.  Otherwise (and without the flag) a unit is one k-mer record of kc_record_longs words.  Units are opaque. */
-int kc_wire_unit(kc_ctx *ctx, int *unit_words, int *unit_records);
+ * *unit_words words holding *unit_records records, and every destination shard gets *pieces pieces: h_counts has
+ * rank_n * *pieces entries, piece j = d * *pieces + q of destination d starts at d_records + j * seg_capacity *
+ * *unit_words and holds h_counts[j] units; seg_capacity counts the units of ONE piece (a block of R reads of length L
+ * needs about R * (L - k - 1) / (rank_n * *pieces * *unit_records) * 1.3 + 4096); kc_insert_records takes units, a piece
+ * or any number of pieces laid end to end, in any order.  Where level 1 writes six-byte records (k = 21 with 1024
+ * level-1 buckets) a unit is three words = four records of six bytes -- the k-mer travels mixed, as level 1 stages it,
+ * so the receiver neither unpacks nor hashes it; a piece is closed to whole units with marker slots -- and the pieces
+ * of a destination hold its records by the top bits of their level-1 bucket (2 to 16 pieces, 128 per sender at most),
+ * which is what makes the receiver's level 1 cheap: a round of its 1024-way split that reads out of one piece meets a
+ * sixteenth of the buckets and appends sixteen times as much to each.  Otherwise (and without the flag) a unit is one
+ * k-mer record of kc_record_longs words and a destination has one piece.  Units are opaque. */
+int kc_wire_unit(kc_ctx *ctx, int *unit_words, int *unit_records, int *pieces);
+/* kc_insert_records for several pieces that lie `piece_stride_units` units apart (piece j at d_records + j *
+ * piece_stride_units * unit_words, h_units[j] units; empty ones are skipped): what a shard keeps for itself of a block it
+ * has extracted -- its own pieces of the send buffer, where they lie.  With wire units one launch takes up to sixteen
+ * pieces (a round of a workgroup reads out of one), so that many small pieces do not become many small launches. */
+int kc_insert_record_pieces(kc_ctx *ctx, const uint64_t *d_records, uint64_t piece_stride_units, int npieces, const uint64_t *h_units);
 /* The shard kc_extract_partition sends a canonical k-mer to (role of KmerDHT::get_kmer_target_rank, kmer_dht.cpp:192-196):
  * kc_owner / kc_owner_reference for k-mer records; eight bits of the mixed k-mer for six-byte wire records (bits only
  * the probe stride of a region table uses, so every shard keeps the whole geometry). */

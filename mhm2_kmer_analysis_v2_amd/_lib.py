@@ -84,8 +84,9 @@ SYMBOLS = {
     "kc_shard_reserve": (C.c_int, [C.c_void_p, C.c_uint64, C.POINTER(C.c_void_p)]),
     "kc_shard_commit": (C.c_int, [C.c_void_p, C.c_void_p, C.c_uint64]),
     "kc_shard_owner": (C.c_int, [C.c_void_p, C.c_void_p, C.POINTER(C.c_int)]),
-    "kc_wire_unit": (C.c_int, [C.c_void_p, C.POINTER(C.c_int), C.POINTER(C.c_int)]),
+    "kc_wire_unit": (C.c_int, [C.c_void_p, C.POINTER(C.c_int), C.POINTER(C.c_int), C.POINTER(C.c_int)]),
     "kc_partition_owner": (C.c_int, [C.c_void_p, C.c_void_p, C.POINTER(C.c_int)]),
+    "kc_insert_record_pieces": (C.c_int, [C.c_void_p, C.c_void_p, C.c_uint64, C.c_int, C.c_void_p]),
     "kc_shard_capacity": (C.c_int, [C.c_void_p, C.POINTER(C.c_uint64)]),
     "kc_build_supermers": (C.c_int, [C.c_void_p, C.c_void_p, C.c_uint64, C.c_int, C.c_void_p, C.c_uint32, C.POINTER(C.c_uint32),
                                       C.POINTER(C.c_uint32), C.c_void_p]),

@@ -132,6 +132,8 @@ struct kc_ctx {
   uint64_t *d_cb, *h_cb;
   bool bk_spilled;       // earlier buffer-fulls of this pass were counted and merged into the global table (bk_spill_pass)
   bool wire6;            // KC_FLAG_WIRE_UNITS and a geometry of six-byte records: kc_extract_partition / kc_insert_records speak kc_wire6.hpp's units
+  uint64_t *d_w6cur;     // ... the sender's cursors, one per (destination, piece); h_w6cur: their host copy
+  uint64_t h_w6cur[WIRE6_MAX_SHARDS << WIRE6_MAX_LG_PIECES];
   bool l1_dropped;       // earlier buffer-fulls of this pass went through level 2 and left level 1 (bk_light_spill): level 2 holds them
   uint64_t l2_held;      // ... that many records (an upper bound)
   uint64_t l2_per_bucket;  // records every bucket's part of the level-2 arena has room for while level 2 runs in instalments
@@ -452,6 +454,7 @@ extern "C" void kc_destroy(kc_ctx *c) {
   free_results(c);
   if (c->arena) (void)hipFree(c->arena);
   if (c->d_ctrs) (void)hipFree(c->d_ctrs);
+  if (c->d_w6cur) (void)hipFree(c->d_w6cur);
   if (c->h_ctrs) (void)hipHostFree(c->h_ctrs);
   if (c->d_tile_first) (void)hipFree(c->d_tile_first);
   if (c->d_out_plan) (void)hipFree(c->d_out_plan);
@@ -1024,6 +1027,15 @@ static int launch_bin_reads_t(kc_ctx *c, const ExtractArgs &a, uint64_t nsuper) 
   return KC_OK;
 }
 
+// pieces per destination of the wire units (kc_wire6.hpp)
+static uint32_t bin_lg_pieces(const kc_ctx *c) {
+  if (!c->wire6) return 0;
+  uint32_t lg = wire6_lg_pieces((uint32_t)c->cfg.rank_n);
+  if (const char *e = getenv("KC_WIRE6_LG_PIECES")) lg = std::min<uint32_t>(lg, (uint32_t)atoi(e));  // (A/B runs)
+  return lg;
+}
+static uint32_t bin_pieces(const kc_ctx *c) { return 1u << bin_lg_pieces(c); }
+
 template <int FMT>
 static int launch_bin16_t(kc_ctx *c, const ExtractArgs &a, uint64_t nsuper) {
   auto kern = kc_bin16_kernel<FMT, 21>;
@@ -1031,7 +1043,7 @@ static int launch_bin16_t(kc_ctx *c, const ExtractArgs &a, uint64_t nsuper) {
   if (rc) return rc;
   const unsigned grid = (unsigned)std::min<uint64_t>((uint64_t)c->num_cus, nsuper);
   KernelTimer kt(c, KT_BIN16);
-  hipLaunchKernelGGL(kern, dim3(grid), dim3(WGB), bin16_lds_bytes(), c->stream, a, c->gm, nsuper, c->d_ctrs);
+  hipLaunchKernelGGL(kern, dim3(grid), dim3(WGB), bin16_lds_bytes(), c->stream, a, c->gm, nsuper, c->d_ctrs, c->d_w6cur, bin_lg_pieces(c));
   return KC_OK;
 }
 
@@ -1100,17 +1112,28 @@ static int launch_l1_records_t(kc_ctx *c, const uint64_t *recs, uint64_t n) {
   return KC_OK;
 }
 
-// level 1 from wire units (kc_wire6.hpp): nslots six-byte slots at `recs`
-static int launch_l1_wire6(kc_ctx *c, const uint8_t *recs, uint64_t nslots) {
+// level 1 from wire units (kc_wire6.hpp): n pieces (<= WIRE6_SRC_PIECES, none empty) of slots[j] six-byte slots at base + j * stride
+static int launch_l1_wire6(kc_ctx *c, const uint8_t *base, uint64_t stride, uint32_t n, const uint64_t *slots) {
   c->gm.own_lo = 0;
   c->gm.own_hi = PMAX;
-  const uint64_t per_round = (uint64_t)WGB * R16;
-  const uint64_t rounds = (nslots + per_round - 1) / per_round;
+  constexpr uint64_t PPR = (uint64_t)WGB * R16 / 2;  // pairs per round
+  Wire6Src src;
+  memset(&src, 0, sizeof(src));
+  src.base = base;
+  src.stride = stride;
+  src.n = n;
+  uint64_t rounds = 0;
+  for (uint32_t j = 0; j < n; j++) {
+    src.rpre[j] = (uint32_t)rounds;
+    src.pairs[j] = (uint32_t)(slots[j] / 2);
+    rounds += (slots[j] / 2 + PPR - 1) / PPR;
+  }
+  src.rpre[n] = (uint32_t)rounds;
   const unsigned grid = (unsigned)std::min<uint64_t>(c->gm.G, rounds);
   int rc = set_dyn_lds(kc_l1_wire6_kernel, l1r16_lds_bytes());
   if (rc) return rc;
   KernelTimer kt(c, KT_L1_WIRE6);
-  hipLaunchKernelGGL(kc_l1_wire6_kernel, dim3(grid), dim3(WGB), l1r16_lds_bytes(), c->stream, recs, nslots, c->gm, c->bb, c->bk_rot, c->d_ctrs, c->d_cb);
+  hipLaunchKernelGGL(kc_l1_wire6_kernel, dim3(grid), dim3(WGB), l1r16_lds_bytes(), c->stream, src, c->gm, c->bb, c->bk_rot, c->d_ctrs, c->d_cb);
   c->bk_rot = (uint32_t)((c->bk_rot + rounds) % c->gm.G);
   return KC_OK;
 }
@@ -1833,17 +1856,28 @@ static int bin_begin(kc_ctx *c) {
     if (rc) return rc;
   }
   HIPCHK(hipMemsetAsync(c->d_ctrs + CTR_OVERFLOW, 0, (1 + 64) * 8, c->stream));
+  if (c->wire6) {
+    if (!c->d_w6cur) HIPCHK(hipMalloc((void **)&c->d_w6cur, sizeof(c->h_w6cur)));
+    HIPCHK(hipMemsetAsync(c->d_w6cur, 0, sizeof(c->h_w6cur), c->stream));
+  }
   return KC_OK;
 }
-static int bin_end(kc_ctx *c, uint64_t seg_capacity, uint64_t *h_counts) {
+static int bin_end(kc_ctx *c, uint64_t *d_records, uint64_t seg_capacity, uint64_t *h_counts) {
+  const uint32_t np = (uint32_t)c->cfg.rank_n * bin_pieces(c);
+  if (c->wire6) {  // every piece closed to whole units
+    hipLaunchKernelGGL(kc_wire6_seal_kernel, dim3((np + 63) / 64), dim3(64), 0, c->stream, c->d_w6cur, np, reinterpret_cast<uint8_t *>(d_records),
+                       seg_capacity * WIRE6_UNIT_RECORDS);
+    c->num_gpu_calls++;
+    HIPCHK(hipGetLastError());
+    HIPCHK(hipMemcpyAsync(c->h_w6cur, c->d_w6cur, (size_t)np * 8, hipMemcpyDeviceToHost, c->stream));
+  }
   int rc = sync_ctrs(c);
   if (rc) return rc;
-  const uint64_t per_unit = c->wire6 ? WIRE6_UNIT_RECORDS : 1;
-  for (int d = 0; d < c->cfg.rank_n; d++) h_counts[d] = c->h_ctrs[CTR_BIN0 + d] / per_unit;
+  for (uint32_t j = 0; j < np; j++) h_counts[j] = c->wire6 ? c->h_w6cur[j] / WIRE6_UNIT_RECORDS : c->h_ctrs[CTR_BIN0 + j];
   if (c->h_ctrs[CTR_BAD_BASE]) return KC_ERR_BAD_BASE;
   if (c->h_ctrs[CTR_OVERFLOW]) {
     snprintf(g_last_error, sizeof(g_last_error), "a shard segment is too small: raise seg_capacity (%llu %s)", (unsigned long long)seg_capacity,
-             c->wire6 ? "units of four records" : "records");
+             c->wire6 ? "units of four records per piece" : "records");
     return KC_ERR_CAPACITY;
   }
   return KC_OK;
@@ -1857,7 +1891,7 @@ extern "C" int kc_extract_partition(kc_ctx *c, const uint8_t *bases, const uint8
   if (rc) return rc;
   rc = submit_reads_impl(c, bases, quals, offsets, nreads, on_device, MODE_BIN, d_records, seg_capacity);
   if (rc) return rc;
-  return bin_end(c, seg_capacity, h_counts);
+  return bin_end(c, d_records, seg_capacity, h_counts);
 }
 
 extern "C" int kc_extract_partition_seq_block(kc_ctx *c, const char *seqs, uint64_t len, int on_device, uint64_t *d_records,
@@ -1876,7 +1910,7 @@ extern "C" int kc_extract_partition_seq_block(kc_ctx *c, const char *seqs, uint6
   }
   rc = run_extract_device(c, d, nullptr, nullptr, 0, len, MODE_BIN, FMT_SEQBLOCK, d_records, seg_capacity);
   if (rc) return rc;
-  return bin_end(c, seg_capacity, h_counts);
+  return bin_end(c, d_records, seg_capacity, h_counts);
 }
 
 template <int NL>
@@ -1957,7 +1991,7 @@ extern "C" int kc_insert_records(kc_ctx *c, const uint64_t *d_records, uint64_t 
             snprintf(g_last_error, sizeof(g_last_error), "overflow list has no room: raise ovf_capacity");
             return KC_ERR_CAPACITY;
           }
-          rc = launch_l1_wire6(c, reinterpret_cast<const uint8_t *>(d_records) + done * 6, m);
+          rc = launch_l1_wire6(c, reinterpret_cast<const uint8_t *>(d_records) + done * 6, 0, 1, &m);
           if (rc) return rc;
           HIPCHK(hipGetLastError());
           done += m;
@@ -1997,8 +2031,66 @@ extern "C" int kc_insert_records(kc_ctx *c, const uint64_t *d_records, uint64_t 
   return table_insert_records(c, d_records, n, 1u);
 }
 
-extern "C" int kc_wire_unit(kc_ctx *c, int *unit_words, int *unit_records) {
-  if (!c || !unit_words || !unit_records) return KC_ERR_INVALID_ARG;
+extern "C" int kc_insert_record_pieces(kc_ctx *c, const uint64_t *d_records, uint64_t piece_stride_units, int npieces, const uint64_t *h_units) {
+  if (!c || npieces < 0 || (npieces && (!d_records || !h_units))) return KC_ERR_INVALID_ARG;
+  if (c->finalized || c->bk_level2 || shard_flow_only(c)) return KC_ERR_STATE;
+  HIPCHK(hipSetDevice(c->cfg.device));
+  if (bk_active(c)) {
+    int rc = bk_init(c);
+    if (rc) return rc;
+  }
+  const uint64_t unit_words = c->wire6 ? WIRE6_UNIT_WORDS : (uint64_t)c->nl;
+  // Wire units on the bucketed path: the pieces that hold anything in launches of up to sixteen -- a round of a workgroup
+  // reads out of one piece --, as long as the buffer and the overflow list take them all; anything else piece by piece
+  // through kc_insert_records, which knows what to do when the buffer is full
+  if (c->wire6 && bk_active(c)) {
+    std::vector<uint64_t> slots, first;
+    uint64_t total = 0;
+    bool small = true;
+    for (int j = 0; j < npieces; j++) {
+      if (!h_units[j]) continue;
+      slots.push_back(h_units[j] * WIRE6_UNIT_RECORDS);
+      first.push_back((uint64_t)j);
+      total += slots.back();
+      small = small && slots.back() < (1ULL << 32);
+    }
+    if (!total) return KC_OK;
+    int rc = sync_ctrs(c);
+    if (rc) return rc;
+    uint64_t room = 0;
+    rc = bk_ovf1_room(c, total, &room);
+    if (rc) return rc;
+    if (small && c->h_ctrs[CTR_EXPECT] - c->expect_base + total <= c->bk_capacity && room >= total) {
+      c->started = true;
+      c->expect_prev = c->h_ctrs[CTR_EXPECT] + total;
+      c->expect_host_ok = false;
+      c->ovf1_ub += total;
+      // pieces that lie at multiples of the stride from the first of a group go in one launch
+      size_t i = 0;
+      while (i < slots.size()) {
+        const size_t n = std::min<size_t>(WIRE6_SRC_PIECES, slots.size() - i);
+        // (the table holds consecutive indices: pieces skipped because they are empty break a group)
+        size_t m = 1;
+        while (m < n && first[i + m] == first[i] + m) m++;
+        rc = launch_l1_wire6(c, reinterpret_cast<const uint8_t *>(d_records + first[i] * piece_stride_units * unit_words),
+                             piece_stride_units * unit_words * 8, (uint32_t)m, &slots[i]);
+        if (rc) return rc;
+        HIPCHK(hipGetLastError());
+        i += m;
+      }
+      return KC_OK;
+    }
+  }
+  for (int j = 0; j < npieces; j++) {
+    if (!h_units[j]) continue;
+    int rc = kc_insert_records(c, d_records + (uint64_t)j * piece_stride_units * unit_words, h_units[j]);
+    if (rc) return rc;
+  }
+  return KC_OK;
+}
+
+extern "C" int kc_wire_unit(kc_ctx *c, int *unit_words, int *unit_records, int *pieces) {
+  if (!c || !unit_words || !unit_records || !pieces) return KC_ERR_INVALID_ARG;
   HIPCHK(hipSetDevice(c->cfg.device));
   if ((c->cfg.flags & KC_FLAG_WIRE_UNITS) && bk_active(c)) {
     int rc = bk_init(c);  // the geometry decides
@@ -2006,6 +2098,7 @@ extern "C" int kc_wire_unit(kc_ctx *c, int *unit_words, int *unit_records) {
   }
   *unit_words = c->wire6 ? (int)WIRE6_UNIT_WORDS : c->nl;
   *unit_records = c->wire6 ? (int)WIRE6_UNIT_RECORDS : 1;
+  *pieces = (int)bin_pieces(c);
   return KC_OK;
 }
 

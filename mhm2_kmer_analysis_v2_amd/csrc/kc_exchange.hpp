@@ -51,6 +51,7 @@ class ShardExchange {
   kc_ctx *ctx;
   ncclComm_t comm;
   int me, n, nl;
+  int Q = 1;                       // RECORDS: pieces per destination (kc_wire_unit), 1 for k-mer records
   uint64_t seg;                    // BUCKETS: words, RECORDS: records per destination segment of a send buffer
   Flow flow;
   hipStream_t compute = nullptr;   // the context's stream (ours unless the caller gave one)
@@ -69,6 +70,7 @@ class ShardExchange {
     bool any = false;
     int buf = 0;
     uint64_t n_own = 0, n_recv = 0;  // RECORDS
+    std::vector<uint64_t> own;       // RECORDS: units of this rank's own pieces
     std::vector<Piece> pieces;       // BUCKETS: the received segments, where they landed
   } pending;
   uint64_t blocks = 0, sent = 0, received = 0;
@@ -108,7 +110,8 @@ class ShardExchange {
       }
       pending.pieces.clear();
     } else {
-      if (pending.n_own) KCX_KC(kc_insert_records(ctx, send[b] + (uint64_t)me * seg * nl, pending.n_own));
+      // this rank's own pieces, straight from the send buffer, in one call
+      if (pending.n_own) KCX_KC(kc_insert_record_pieces(ctx, send[b] + (uint64_t)me * Q * seg * nl, seg, Q, pending.own.data()));
       // always: the extraction of two blocks on overwrites send[b] on this stream, and the side stream's ncclSend of
       // this block may still be reading it -- also when this rank received nothing
       KCX_HIP(hipStreamWaitEvent(compute, arrived[b], 0));
@@ -125,16 +128,18 @@ class ShardExchange {
   // tuning on every rank); num_longs: kc_record_longs(k) -- for RECORDS with contexts created with KC_FLAG_WIRE_UNITS the
   // words of a unit (kc_wire_unit), and seg_capacity in units --; seg_capacity: what one block may send to one shard, in WORDS
   // for BUCKETS (a block of R reads of length L needs about R * (L - k - 1) / rank_n * num_longs * 1.1 + 1024), in
-  // RECORDS for RECORDS (R * (L - k - 1) / rank_n * 1.25); compute_stream: the stream the context's kernels should run
+  // RECORDS for RECORDS (R * (L - k - 1) / rank_n * 1.25; with wire units: units per PIECE, and `pieces` the pieces per
+  // destination, both from kc_wire_unit); compute_stream: the stream the context's kernels should run
   // on, NULL = a stream of this object's own.
   ShardExchange(kc_ctx *ctx_, ncclComm_t comm_, int rank_me, int rank_n, int num_longs, uint64_t seg_capacity,
-                hipStream_t compute_stream = nullptr, Flow flow_ = BUCKETS)
-      : ctx(ctx_), comm(comm_), me(rank_me), n(rank_n), nl(num_longs), seg(seg_capacity), flow(flow_), compute(compute_stream) {}
+                hipStream_t compute_stream = nullptr, Flow flow_ = BUCKETS, int pieces = 1)
+      : ctx(ctx_), comm(comm_), me(rank_me), n(rank_n), nl(num_longs), Q(flow_ == RECORDS ? pieces : 1), seg(seg_capacity), flow(flow_),
+        compute(compute_stream) {}
   ShardExchange(const ShardExchange &) = delete;
   ShardExchange &operator=(const ShardExchange &) = delete;
 
   int init() {
-    if (!ctx || n < 1 || me < 0 || me >= n || nl < 1 || !seg) return fail(KC_ERR_INVALID_ARG, "ShardExchange", "bad arguments");
+    if (!ctx || n < 1 || me < 0 || me >= n || nl < 1 || !seg || Q < 1) return fail(KC_ERR_INVALID_ARG, "ShardExchange", "bad arguments");
     if (!compute) {
       KCX_HIP(hipStreamCreateWithFlags(&compute, hipStreamNonBlocking));
       own_compute = true;
@@ -142,14 +147,14 @@ class ShardExchange {
     KCX_KC(kc_set_stream(ctx, (void *)compute));
     KCX_HIP(hipStreamCreateWithFlags(&side, hipStreamNonBlocking));
     for (int b = 0; b < 2; b++) {
-      KCX_HIP(hipMalloc((void **)&send[b], (size_t)n * seg * (flow == BUCKETS ? 1 : nl) * 8));
+      KCX_HIP(hipMalloc((void **)&send[b], (size_t)n * Q * seg * (flow == BUCKETS ? 1 : nl) * 8));
       KCX_HIP(hipEventCreateWithFlags(&arrived[b], hipEventDisableTiming));
       KCX_HIP(hipEventCreateWithFlags(&consumed[b], hipEventDisableTiming));
     }
     KCX_HIP(hipEventCreateWithFlags(&extracted, hipEventDisableTiming));
-    KCX_HIP(hipMalloc((void **)&d_counts, (size_t)n * 8));
-    KCX_HIP(hipMalloc((void **)&d_all, (size_t)n * n * 8));
-    KCX_HIP(hipHostMalloc((void **)&h_all, (size_t)n * n * 8, hipHostMallocDefault));
+    KCX_HIP(hipMalloc((void **)&d_counts, (size_t)n * Q * 8));
+    KCX_HIP(hipMalloc((void **)&d_all, (size_t)n * n * Q * 8));
+    KCX_HIP(hipHostMalloc((void **)&h_all, (size_t)n * n * Q * 8, hipHostMallocDefault));
     return KC_OK;
   }
 
@@ -184,7 +189,8 @@ class ShardExchange {
       if (flow == BUCKETS) KCX_HIP(hipEventSynchronize(arrived[b]));  // the kernels below overwrite it at once
       // RECORDS: the extraction is ordered behind those inserts by the compute stream itself
     }
-    std::vector<uint64_t> counts((size_t)n, 0);
+    const size_t NQ = (size_t)n * Q;  // sizes per rank: one per destination (BUCKETS), one per piece of every destination (RECORDS)
+    std::vector<uint64_t> counts(NQ, 0);
     // A rank whose extraction fails (a segment too small, a bad character) must not leave the others waiting in the
     // exchange of the sizes: it takes part with a size no block can have, and every rank returns an error together.
     int local_rc = KC_OK;
@@ -203,17 +209,22 @@ class ShardExchange {
     KCX_HIP(hipEventRecord(extracted, compute));
     KCX_HIP(hipStreamWaitEvent(side, extracted, 0));
     // everybody's sizes: N x N, row s = what rank s sends to each shard
-    KCX_HIP(hipMemcpyAsync(d_counts, counts.data(), (size_t)n * 8, hipMemcpyHostToDevice, side));
-    KCX_NCCL(ncclAllGather(d_counts, d_all, (size_t)n, ncclUint64, comm, side));
-    KCX_HIP(hipMemcpyAsync(h_all, d_all, (size_t)n * n * 8, hipMemcpyDeviceToHost, side));
+    KCX_HIP(hipMemcpyAsync(d_counts, counts.data(), NQ * 8, hipMemcpyHostToDevice, side));
+    KCX_NCCL(ncclAllGather(d_counts, d_all, NQ, ncclUint64, comm, side));
+    KCX_HIP(hipMemcpyAsync(h_all, d_all, (size_t)n * NQ * 8, hipMemcpyDeviceToHost, side));
     KCX_HIP(hipStreamSynchronize(side));
     if (local_rc != KC_OK) return local_rc;
-    for (size_t i = 0; i < (size_t)n * n; i++)
+    for (size_t i = 0; i < (size_t)n * NQ; i++)
       if (h_all[i] == POISON) return fail(KC_ERR_STATE, "ShardExchange::add_block", "another rank failed to extract its block");
     const uint64_t unit = flow == BUCKETS ? 1 : (uint64_t)nl;  // words per counted thing
     uint64_t total = 0;  // BUCKETS: every sender's part starts on a 16-byte boundary
-    for (int s = 0; s < n; s++)
-      if (s != me) total += flow == BUCKETS ? ((h_all[(size_t)s * n + me] + 1) & ~1ULL) : h_all[(size_t)s * n + me];
+    for (int s = 0; s < n; s++) {
+      if (s == me) continue;
+      for (int q = 0; q < Q; q++) {
+        const uint64_t w = h_all[(size_t)s * NQ + (size_t)me * Q + q];
+        total += flow == BUCKETS ? ((w + 1) & ~1ULL) : w;
+      }
+    }
     uint64_t *dst = nullptr;
     if (flow == BUCKETS) {
       KCX_KC(kc_shard_reserve(ctx, total, &dst));  // inside the context, for good: level 2 reads it in place
@@ -233,17 +244,29 @@ class ShardExchange {
     // all-to-all-v: one group of point-to-point transfers (each pair has its own xGMI link)
     if (flow == RECORDS && used[b]) KCX_HIP(hipStreamWaitEvent(side, consumed[b], 0));
     KCX_NCCL(ncclGroupStart());
+    // where every piece lands: piece 0 of every sender first, then piece 1, ... -- what lies side by side then holds the
+    // same level-1 buckets, which is what the receiver's level 1 wants (kc_wire6.hpp)
+    std::vector<uint64_t> at(NQ, 0);
     uint64_t pos = 0;
+    for (int q = 0; q < Q; q++)
+      for (int d = 0; d < n; d++) {
+        if (d == me) continue;
+        const uint64_t rcv = h_all[(size_t)d * NQ + (size_t)me * Q + q];
+        at[(size_t)d * Q + q] = pos;
+        pos += flow == BUCKETS ? ((rcv + 1) & ~1ULL) : rcv;
+      }
     for (int d = 0; d < n; d++) {
       if (d == me) continue;  // this rank's own share never travels
-      const uint64_t sc = counts[(size_t)d], rcv = h_all[(size_t)d * n + me];
-      if (rcv) {
-        KCX_NCCL(ncclRecv(dst + pos * unit, (size_t)rcv * unit, ncclUint64, d, comm, side));
-        if (flow == BUCKETS) pending.pieces.push_back(Piece{dst + pos, rcv});
+      for (int q = 0; q < Q; q++) {  // (both sides post a peer's pieces in the same order)
+        const size_t j = (size_t)d * Q + q;
+        const uint64_t sc = counts[j], rcv = h_all[(size_t)d * NQ + (size_t)me * Q + q];
+        if (rcv) {
+          KCX_NCCL(ncclRecv(dst + at[j] * unit, (size_t)rcv * unit, ncclUint64, d, comm, side));
+          if (flow == BUCKETS) pending.pieces.push_back(Piece{dst + at[j], rcv});
+        }
+        if (sc) KCX_NCCL(ncclSend(send[b] + (uint64_t)j * seg * unit, (size_t)sc * unit, ncclUint64, d, comm, side));
+        sent += sc;
       }
-      if (sc) KCX_NCCL(ncclSend(send[b] + (uint64_t)d * seg * unit, (size_t)sc * unit, ncclUint64, d, comm, side));
-      pos += flow == BUCKETS ? ((rcv + 1) & ~1ULL) : rcv;
-      sent += sc;
     }
     KCX_NCCL(ncclGroupEnd());
     KCX_HIP(hipEventRecord(arrived[b], side));
@@ -251,8 +274,10 @@ class ShardExchange {
     pending.any = true;
     pending.buf = b;
     if (flow == RECORDS) {
-      sent += counts[(size_t)me];
-      pending.n_own = counts[(size_t)me];
+      pending.own.assign(counts.begin() + (size_t)me * Q, counts.begin() + (size_t)(me + 1) * Q);
+      pending.n_own = 0;
+      for (uint64_t v : pending.own) pending.n_own += v;
+      sent += pending.n_own;
       pending.n_recv = total;
     }
     return KC_OK;

@@ -11,15 +11,18 @@
 //   sender    kc_bin16_kernel      level 1's super-tile staging and cut (cp_run_fixed: sixteen k-mers per thread, already
 //                                  MIXED), the owner shard taken from eight bits of the mix (wire6_owner: bits that only
 //                                  the probe stride of the region tables uses -- buckets, regions and start slots keep
-//                                  all of theirs, so every shard uses the whole geometry), ranked with LDS adds over
-//                                  owner x sub-counter cells (a handful of owners alone would serialise the adds),
-//                                  staged sorted by owner in six bytes, copied out as 12-byte pairs in long runs
+//                                  all of theirs, so every shard uses the whole geometry), the PIECE from the top bits of
+//                                  the level-1 bucket (below), ranked with LDS adds over (owner, piece) x lane-cell
+//                                  counters (a handful of cells alone would serialise the adds), staged sorted by (owner,
+//                                  piece) in six bytes, copied out as 12-byte pairs in runs of hundreds of records
 //   wire      SIX bytes a record   the 32 bits of the mix below the bucket + bucket | extension codes << 10: what level 1
-//                                  stages.  The unit of the exchange is FOUR records = three words, every run a sender
-//                                  appends to a segment is padded to whole units with marker slots (bk = 0xFFFF), so that
-//                                  segments of whole words can be shipped and laid end to end
+//                                  stages.  The unit of the exchange is FOUR records = three words; a run a sender appends
+//                                  is padded to an even length and a piece is closed to whole units with marker slots
+//                                  (bk = 0xFFFF; 0.1 % of the slots), so that pieces of whole words can be shipped and
+//                                  laid end to end
 //   receiver  kc_l1_wire6_kernel   level 1 from received records: nothing to unpack, mix or hash -- a 12-byte load per
-//                                  pair, the bucket is ten bits of the record; staging and copy-out are level 1's own
+//                                  pair, the bucket is ten bits of the record; staging and copy-out are level 1's own.
+//                                  It reads up to sixteen pieces per launch, a round of a workgroup out of one piece
 //
 // A record is written once more than in the unsharded pass (the wire segment) and read once more.
 #pragma once
@@ -33,24 +36,41 @@ constexpr uint32_t WIRE6_MAX_SHARDS = 64;
 
 // owner shard of a mixed k-mer: bits 13..20 of the mix, scaled to [0, n)
 __host__ __device__ __forceinline__ uint32_t wire6_owner(uint32_t lo, uint32_t n) { return (((lo >> 13) & 255u) * n) >> 8; }
-// the smallest value of those eight bits that owner o has, in place (a marker slot must land in its owner's run)
-__host__ __device__ __forceinline__ uint32_t wire6_marker_lo(uint32_t o, uint32_t n) { return ((o * 256u + n - 1u) / n) << 13; }
 
 constexpr size_t bin16_lds_bytes() { return l1x16_lds_bytes(); }
 
-// cursors[d]: slots appended to segment d so far (a multiple of four); segment d starts at records + d * seg_units * 3 words
+// Pieces per destination: the sender keeps a destination's records apart by the top bits of their level-1 BUCKET, one piece
+// per value.  The receiver's level 1 is bound by the store requests of its 1024-way split -- sixteen records per bucket and
+// round are runs of 96 bytes that touch 1.75 lines each -- and it reads what it receives front to back: a round that
+// comes out of ONE piece of eight meets 128 buckets instead of 1024, its runs are 128 records long, and the requests
+// per record drop to little more than the lines the records fill: 26 -> 18 ms per 50 M reads (profiles/r04_ab_wire6_pieces.txt;
+// two pieces 20.9, four 18.5, eight 17.8, sixteen 17.9).  The sender sorts by (owner, piece) instead of by owner at the
+// price of a few instructions per record (21.1 -> 22.1 ms).  128 (owner, piece) cells at most, so that the sender's own
+// runs stay long.
+constexpr uint32_t WIRE6_MAX_LG_PIECES = 3;  // (sixteen measured no better than eight)
+__host__ __device__ __forceinline__ uint32_t wire6_ceil_log2(uint32_t n) {
+  uint32_t l = 0;
+  while ((1u << l) < n) l++;
+  return l;
+}
+__host__ __device__ __forceinline__ uint32_t wire6_lg_pieces(uint32_t nshards) {
+  const uint32_t lg = wire6_ceil_log2(nshards);
+  return lg >= 7u ? 0u : min(WIRE6_MAX_LG_PIECES, 7u - lg);
+}
+
+// cur[d << lgQ | q]: slots appended to piece q of destination d so far (even); the piece starts at
+// records + (d << lgQ | q) * seg_units * 3 words and holds seg_units * 4 slots
 template <int FMT, int KK>
-__global__ __launch_bounds__(WGB) void kc_bin16_kernel(ExtractArgs a, Geom gm, uint64_t nsuper, uint64_t *ctrs) {
+__global__ __launch_bounds__(WGB) void kc_bin16_kernel(ExtractArgs a, Geom gm, uint64_t nsuper, uint64_t *ctrs, uint64_t *cur, uint32_t lgQ) {
   extern __shared__ __align__(16) uint8_t smem[];
   L1LDS &L = *reinterpret_cast<L1LDS *>(smem);
   uint32_t *slo = reinterpret_cast<uint32_t *>(smem + ((sizeof(L1LDS) + 15) & ~size_t(15)));
   uint16_t *sbk = reinterpret_cast<uint16_t *>(slo + ST16_SLOTS);
   const int tid = threadIdx.x;
   const uint32_t P = a.rank_n;  // <= WIRE6_MAX_SHARDS
-  // cells per owner: as many as keep owner x cell within the histogram and a cell's lanes within a wave
-  uint32_t lgP = 0;
-  while ((1u << lgP) < P) lgP++;
-  const uint32_t lgS = min(6u, 10u - lgP), SUBm = (1u << lgS) - 1u, V = P << lgS;
+  const uint32_t qsh = gm.la - lgQ, V = P << lgQ;  // V (owner, piece) cells, <= 128 (lgQ = wire6_lg_pieces(P))
+  // lane cells per (owner, piece): LDS adds of a wave to a handful of words would be serialised
+  const uint32_t lgV = wire6_ceil_log2(V), lgS = lgV >= 7u ? 0u : 7u - lgV, SUBm = (1u << lgS) - 1u, NV = V << lgS;
   for (uint32_t i = (uint32_t)tid; i < PMAX + 64; i += WGB) {
     L.sp.hist[0][i] = 0;
     L.sp.hist[1][i] = 0;
@@ -69,9 +89,10 @@ __global__ __launch_bounds__(WGB) void kc_bin16_kernel(ExtractArgs a, Geom gm, u
                                   (uint64_t)blockIdx.x + gridDim.x < nsuper);
     next_first = first_of((uint64_t)blockIdx.x + 2 * (uint64_t)gridDim.x);
   }
-  const uint64_t seg_slots = a.seg_capacity * WIRE6_UNIT_RECORDS;
+  const uint64_t piece_slots = a.seg_capacity * WIRE6_UNIT_RECORDS;
   uint8_t *const out0 = reinterpret_cast<uint8_t *>(a.records);
-  const uint32_t cell = lane_id() & SUBm;
+  const uint32_t lcell = lane_id() & SUBm;
+  auto cell_of = [&](uint32_t lo32, uint32_t bk16) -> uint32_t { return (wire6_owner(lo32, P) << lgQ) | ((bk16 & (PMAX - 1)) >> qsh); };
   for (uint64_t st = blockIdx.x; st < nsuper; st += gridDim.x) {
     uint32_t lo[R16], br[R16];
     const bool active = tid < RUNS;
@@ -94,8 +115,8 @@ __global__ __launch_bounds__(WGB) void kc_bin16_kernel(ExtractArgs a, Geom gm, u
 #pragma unroll
     for (int j = 0; j < R16; j++) {
       const bool valid = br[j] != ~0u;
-      const uint32_t vb = (wire6_owner(lo[j], P) << lgS) | cell;
-      const uint32_t rank = hist_rank(L.sp, buf, vb, valid);
+      const uint32_t vb = (cell_of(lo[j], br[j]) << lgS) | lcell;
+      const uint32_t rank = hist_rank(L.sp, buf, valid ? vb : 0u, valid);
       // (both extensions missing with all their ignored low bits set, in the last bucket, would read as a marker: a missing
       // extension is any code >= 4, so the left one's lowest bit is dropped there)
       const uint32_t b16 = br[j] & 0xFFFFu;
@@ -105,41 +126,39 @@ __global__ __launch_bounds__(WGB) void kc_bin16_kernel(ExtractArgs a, Geom gm, u
     const int ft = fresh_tid();
     const uint64_t nst = st + gridDim.x;
     tile_encode_clear<TileSuper>(L.tile, raw, ft);
-    // scan + reserve: thread t < V has cell t of owner t >> lgS; an owner's cells lie side by side in the staging, its run
-    // is padded to whole units (marker slots behind the last cell's records)
+    // scan + reserve: thread t < NV has lane cell t & SUBm of (owner, piece) cell t >> lgS; a cell's lane cells lie side by
+    // side in the staging, its run starts on an even position and is padded to an even length (one marker slot), so that
+    // the copy-out takes pairs and a pair never straddles two cells
     {
-      const uint32_t v = ((uint32_t)ft < V) ? L.sp.hist[buf][ft] : 0u;
-      uint32_t own_total = v;  // over the owner's cells (consecutive lanes of one wave)
-      for (uint32_t o = 1; o <= SUBm; o <<= 1) own_total += (uint32_t)__shfl_xor((int)own_total, (int)o);
-      const uint32_t pad = (0u - own_total) & (WIRE6_UNIT_RECORDS - 1u);
-      const bool last_cell = ((uint32_t)ft & SUBm) == SUBm;
-      const uint32_t excl = block_excl_scan(v + (((uint32_t)ft < V && last_cell) ? pad : 0u), L.sp.scan);
-      const uint32_t own_start = (uint32_t)__shfl((int)excl, (int)(lane_id() & ~SUBm));
-      if ((uint32_t)ft < V) {
-        const uint32_t o = (uint32_t)ft >> lgS;
+      const uint32_t v = ((uint32_t)ft < NV) ? L.sp.hist[buf][ft] : 0u;
+      uint32_t run_total = v;  // over the cell's lane cells (consecutive lanes of one wave)
+      for (uint32_t o = 1; o <= SUBm; o <<= 1) run_total += (uint32_t)__shfl_xor((int)run_total, (int)o);
+      const uint32_t pad = run_total & 1u;
+      const bool last_lane_cell = ((uint32_t)ft & SUBm) == SUBm;
+      const uint32_t excl = block_excl_scan(v + (((uint32_t)ft < NV && last_lane_cell) ? pad : 0u), L.sp.scan);
+      const uint32_t run_start = (uint32_t)__shfl((int)excl, (int)(lane_id() & ~SUBm));
+      if ((uint32_t)ft < NV) {
+        const uint32_t dq = (uint32_t)ft >> lgS;
         if (((uint32_t)ft & SUBm) == 0) {
-          const uint32_t want = own_total + pad;
+          const uint32_t want = run_total + pad;
           uint64_t base = 0;
-          if (want) base = atomicAdd((unsigned long long *)&ctrs[CTR_BIN0 + o], (unsigned long long)want);
-          const bool ok = base + want <= seg_slots;
+          if (want) base = atomicAdd((unsigned long long *)&cur[dq], (unsigned long long)want);
+          const bool ok = base + want + 2 <= piece_slots;  // (two slots stay free for kc_wire6_seal_kernel)
           if (!ok) ctrs[CTR_OVERFLOW] = 1;
-          const uint64_t delta = (uint64_t)o * seg_slots + base - own_start;  // slot in the whole buffer = delta + staging position
+          const uint64_t delta = (uint64_t)dq * piece_slots + base - run_start;  // slot in the whole buffer = delta + staging position
           uint4 d;
           d.x = (uint32_t)delta;
           d.y = (uint32_t)(delta >> 32);
           d.z = ok ? 1u : 0u;
           d.w = 0;
-          L.sp.dst[o] = d;
+          L.sp.dst[dq] = d;
         }
-        if (last_cell) {
-          const uint32_t mlo = wire6_marker_lo(o, P);
-          for (uint32_t i = 0; i < pad; i++) {
-            slo[excl + v + i] = mlo;
-            sbk[excl + v + i] = (uint16_t)WIRE6_MARK;
-          }
+        if (last_lane_cell && pad) {
+          slo[excl + v] = 0;
+          sbk[excl + v] = (uint16_t)WIRE6_MARK;
         }
-        L.sp.hist[buf][ft] = excl;      // where the cell's records start in the staging
-        L.sp.hist[buf ^ 1][ft] = 0;     // next round's histogram
+        L.sp.hist[buf][ft] = excl;   // where the lane cell's records start in the staging
+        L.sp.hist[buf ^ 1][ft] = 0;  // next round's histogram
       }
     }
     lds_barrier();
@@ -148,7 +167,10 @@ __global__ __launch_bounds__(WGB) void kc_bin16_kernel(ExtractArgs a, Geom gm, u
     for (int j0 = 0; j0 < R16; j0 += 8) {
       uint32_t pos[8];
 #pragma unroll
-      for (int j = 0; j < 8; j++) pos[j] = L.sp.hist[buf][(wire6_owner(lo[j0 + j], P) << lgS) | cell];
+      for (int j = 0; j < 8; j++) {
+        const uint32_t bj = br[j0 + j];
+        pos[j] = L.sp.hist[buf][bj != ~0u ? ((cell_of(lo[j0 + j], bj) << lgS) | lcell) : 0u];
+      }
 #pragma unroll
       for (int j = 0; j < 8; j++) {
         const uint32_t bj = br[j0 + j];
@@ -161,14 +183,14 @@ __global__ __launch_bounds__(WGB) void kc_bin16_kernel(ExtractArgs a, Geom gm, u
     tile_prefetch<FMT, TileSuper>(raw, a, a.pos0 + (int64_t)(nst + gridDim.x) * SUPER_SPAN, ft, next_first, nst + gridDim.x < nsuper);
     next_first = first_of(nst + 2 * (uint64_t)gridDim.x);
     lds_barrier();
-    // copy-out: the staging two slots at a time; an owner's run is a whole number of units, so a pair never straddles two
-    // owners and always holds two slots (records or markers)
+    // copy-out: the staging two slots at a time; a pair's first slot is always a record (runs start on even positions, a
+    // marker only ever closes a run) and names the pair's cell
     {
       const int ct = fresh_tid();
       for (uint32_t i = 2u * (uint32_t)ct; i < total; i += 2u * WGB) {
         const uint64_t lo2 = *reinterpret_cast<const uint64_t *>(slo + i);
         const uint32_t bk2 = *reinterpret_cast<const uint32_t *>(sbk + i);
-        const uint4 d = L.sp.dst[wire6_owner((uint32_t)lo2, P)];
+        const uint4 d = L.sp.dst[cell_of((uint32_t)lo2, bk2)];
         if (d.z) {
           const uint64_t at = (((uint64_t)d.y << 32) | d.x) + i;
           const uint32_t l1 = (uint32_t)(lo2 >> 32);
@@ -184,10 +206,35 @@ __global__ __launch_bounds__(WGB) void kc_bin16_kernel(ExtractArgs a, Geom gm, u
   }
 }
 
+// behind the sender: every piece is closed to whole units (a piece's length is even: at most one pair of marker slots)
+__global__ void kc_wire6_seal_kernel(uint64_t *cur, uint32_t npieces, uint8_t *out0, uint64_t piece_slots) {
+  const uint32_t j = blockIdx.x * blockDim.x + threadIdx.x;
+  if (j >= npieces) return;
+  const uint64_t c = cur[j];
+  if ((c & 3u) == 0 || c + 2 > piece_slots) return;  // (an overflowing piece has been reported already)
+  Rec6Pair r;
+  r.w0 = 0;
+  r.w1 = WIRE6_MARK;
+  r.w2 = WIRE6_MARK << 16;
+  *reinterpret_cast<Rec6Pair *>(out0 + ((uint64_t)j * piece_slots + c) * 6) = r;
+  cur[j] = c + 2;
+}
+
 // ---- receiver: level 1 from wire records ---------------------------------------------------------------------------------
-// recs: nslots slots of six bytes (a multiple of four; marker slots among them), 4-byte aligned
-__global__ __launch_bounds__(WGB) void kc_l1_wire6_kernel(const uint8_t *recs, uint64_t nslots, Geom gm, BucketBufs bb, uint32_t rot, uint64_t *ctrs,
-                                                          uint64_t *cb) {
+// What one launch reads: up to sixteen pieces, piece j = `pairs[j]` pairs of six-byte slots (marker slots among them) at
+// base + j * stride, 4-byte aligned.  A round of a workgroup comes out of ONE piece (rpre[j]: rounds before piece j; a
+// piece's last round may be short), so that a sender's pieces -- which lie apart in its buffer -- cost one launch, not one
+// each, and nothing has to be looked up per record.
+constexpr int WIRE6_SRC_PIECES = 16;
+struct Wire6Src {
+  const uint8_t *base;
+  uint64_t stride;  // bytes
+  uint32_t n;       // pieces, every one with at least one pair
+  uint32_t rpre[WIRE6_SRC_PIECES + 1];
+  uint32_t pairs[WIRE6_SRC_PIECES];
+};
+
+__global__ __launch_bounds__(WGB) void kc_l1_wire6_kernel(Wire6Src src, Geom gm, BucketBufs bb, uint32_t rot, uint64_t *ctrs, uint64_t *cb) {
   extern __shared__ __align__(16) uint8_t smem[];
   L1RLDS &L = *reinterpret_cast<L1RLDS *>(smem);
   uint32_t *slo = reinterpret_cast<uint32_t *>(smem + ((sizeof(L1RLDS) + 15) & ~size_t(15)));
@@ -203,21 +250,29 @@ __global__ __launch_bounds__(WGB) void kc_l1_wire6_kernel(const uint8_t *recs, u
   ChainState cst = split_load_state(L.sp, P1, bb.cnt1 + (size_t)g * P1, D.chain, D.LMAX, D.log2CH, bb.used1[g], bb.used1[gm.G + g]);
   __syncthreads();
   constexpr int NPAIR = R16 / 2;
-  const uint64_t npairs = nslots / 2, pairs_per_round = (uint64_t)WGB * NPAIR;
-  const uint64_t nrounds = (npairs + pairs_per_round - 1) / pairs_per_round;
+  constexpr uint32_t PPR = (uint32_t)WGB * NPAIR;  // pairs per round
+  const uint32_t nrounds = src.rpre[src.n];
   uint32_t n_ins = 0;
   int buf = 0;
   Load12 nxt[NPAIR];  // the next round's pairs, on their way while this round is split
-  auto load_round = [&](uint64_t rd) {  // npairs > 0; no branches around the loads (a lane past the end re-reads the last pair)
+  uint32_t lim_nxt = 0, lim = 0;  // pairs the round holds (the same for every thread)
+  auto load_round = [&](uint64_t rd) {  // no branches around the loads (a lane past the end re-reads the piece's last pair)
+    uint32_t j = 0;
+    const uint32_t r = rd < nrounds ? (uint32_t)rd : nrounds - 1;
+    for (uint32_t q = 1; q < src.n; q++) j += r >= src.rpre[q] ? 1u : 0u;
+    const uint32_t first = (r - src.rpre[j]) * PPR, np = src.pairs[j];
+    lim_nxt = rd < nrounds ? min(PPR, np - first) : 0u;
+    const uint8_t *pb = src.base + (uint64_t)j * src.stride;
 #pragma unroll
     for (int u = 0; u < NPAIR; u++) {
-      uint64_t p = rd * pairs_per_round + (uint64_t)u * WGB + tid;
-      p = p < npairs ? p : npairs - 1;
-      nxt[u] = *reinterpret_cast<const Load12 *>(recs + p * 12);
+      uint32_t p = first + (uint32_t)u * WGB + (uint32_t)tid;
+      p = p < np ? p : np - 1;
+      nxt[u] = *reinterpret_cast<const Load12 *>(pb + (uint64_t)p * 12);
     }
   };
   uint32_t lo[R16], br[R16];
   auto take_over = [&]() {
+    lim = lim_nxt;
 #pragma unroll
     for (int u = 0; u < NPAIR; u++) {
       const Load12 w = nxt[u];
@@ -227,13 +282,13 @@ __global__ __launch_bounds__(WGB) void kc_l1_wire6_kernel(const uint8_t *recs, u
       br[2 * u + 1] = w.c >> 16;
     }
   };
-  if (npairs) load_round(blockIdx.x);
+  load_round(blockIdx.x);
   take_over();
-  if (npairs) load_round((uint64_t)blockIdx.x + gridDim.x);
+  load_round((uint64_t)blockIdx.x + gridDim.x);
   for (uint64_t rd = blockIdx.x; rd < nrounds; rd += gridDim.x) {
 #pragma unroll
     for (int j = 0; j < R16; j++) {
-      const bool valid = rd * pairs_per_round + (uint64_t)(j >> 1) * WGB + tid < npairs && br[j] != WIRE6_MARK;
+      const bool valid = (uint32_t)(j >> 1) * WGB + (uint32_t)tid < lim && br[j] != WIRE6_MARK;
       const uint32_t rank = hist_rank(L.sp, buf, br[j] & (PMAX - 1), valid);
       br[j] = valid ? (br[j] | (rank << 16)) : ~0u;
       n_ins += valid ? 1u : 0u;

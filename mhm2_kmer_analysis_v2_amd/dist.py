@@ -20,30 +20,35 @@ import torch.distributed as dist
 
 
 def exchange_counts(send_counts, group=None):
-    """send_counts: int64 tensor [world] (records for each destination).  Returns recv_counts [world]."""
+    """send_counts: int64 tensor [world * pieces] (units of every piece, destination after destination).  Returns what
+    every sender has for this rank, sender after sender."""
     recv = torch.empty_like(send_counts)
     dist.all_to_all_single(recv, send_counts, group=group)
     return recv
 
 
-def start_exchange(send, send_counts, recv_counts, seg_capacity, num_longs, recv=None, group=None, reserve=None):
-    """Begin the all-to-all-v of one block.  send: int64 tensor laid out as world segments of seg_capacity units
-    (num_longs words each), the first send_counts[d] units of segment d being valid.  Returns
-    (works, recv tensor, n_received, pieces): what the OTHER ranks sent, once every work has been waited for; pieces =
-    [(first word, words)] per sender.  Without `reserve` the parts are packed back to back in `recv` (grown as needed);
-    with it (the single-pass flow: reserve(nwords) -> tensor inside the receiving context) every part starts on a
-    16-byte boundary of a fresh reservation.  The rank's own share stays where it is: local_share(...) is its view."""
+def start_exchange(send, send_counts, recv_counts, seg_capacity, num_longs, recv=None, group=None, reserve=None, pieces=1):
+    """Begin the all-to-all-v of one block.  send: int64 tensor laid out as world * pieces pieces of seg_capacity units
+    (num_longs words each), the first send_counts[d * pieces + q] units of piece q of destination d being valid
+    (pieces > 1: the wire units of kc_wire_unit, whose sender keeps a destination's records apart by the top bits of their
+    level-1 bucket).  Returns (works, recv tensor, n_received, parts): what the OTHER ranks sent, once every work has been
+    waited for; parts = [(first word, words)] per received piece.  Without `reserve` the parts are packed back to back in
+    `recv` (grown as needed), piece 0 of every sender first, then piece 1, ...: what lies side by side then holds the
+    same buckets, which is what the receiver's level 1 wants; with `reserve` (the single-pass flow: reserve(nwords) ->
+    tensor inside the receiving context) every part starts on a 16-byte boundary of a fresh reservation.  The rank's own
+    share stays where it is: local_share(...) is its view."""
     world = dist.get_world_size(group)
     me = dist.get_rank(group)
     sc = [int(x) for x in send_counts.tolist()]
     rc = [int(x) for x in recv_counts.tolist()]
     align = 2 if reserve is not None else 1
-    starts, pos = [], 0
-    for d in range(world):
-        starts.append(pos)
-        if d != me:
-            pos += (rc[d] * num_longs + align - 1) // align * align
-    total = sum(rc) - rc[me]  # what arrives from the other ranks
+    starts, pos = {}, 0
+    for q in range(pieces):
+        for d in range(world):
+            if d != me:
+                starts[(d, q)] = pos
+                pos += (rc[d * pieces + q] * num_longs + align - 1) // align * align
+    total = sum(rc) - sum(rc[me * pieces:(me + 1) * pieces])  # what arrives from the other ranks
     if reserve is not None:
         recv = reserve(pos)
     elif recv is None or recv.numel() < max(pos, 1):
@@ -51,37 +56,42 @@ def start_exchange(send, send_counts, recv_counts, seg_capacity, num_longs, recv
     # all-to-all-v as one group of point-to-point transfers (RCCL: a single ncclGroup of
     # ncclSend/ncclRecv over xGMI; gloo: the same ops over TCP).  The segments of `send` are not
     # contiguous, so a single-buffer all_to_all_single would need an extra packing pass over HBM.
-    ops, pieces = [], []
+    ops, parts = [], []
     for d in range(world):
         if d == me:
             continue  # this rank's own share never travels
-        base = d * seg_capacity * num_longs
-        src = send[base:base + sc[d] * num_longs]
-        dst = recv[starts[d]:starts[d] + rc[d] * num_longs]
         peer = dist.get_global_rank(group, d) if group is not None else d
-        if rc[d]:
-            ops.append(dist.P2POp(dist.irecv, dst, peer, group))
-            pieces.append((starts[d], rc[d] * num_longs))
-        if sc[d]:
-            ops.append(dist.P2POp(dist.isend, src, peer, group))
+        for q in range(pieces):  # (both sides post a peer's pieces in the same order)
+            j = d * pieces + q
+            base = j * seg_capacity * num_longs
+            src = send[base:base + sc[j] * num_longs]
+            dst = recv[starts[(d, q)]:starts[(d, q)] + rc[j] * num_longs]
+            if rc[j]:
+                ops.append(dist.P2POp(dist.irecv, dst, peer, group))
+                parts.append((starts[(d, q)], rc[j] * num_longs))
+            if sc[j]:
+                ops.append(dist.P2POp(dist.isend, src, peer, group))
     works = dist.batch_isend_irecv(ops) if ops else []
-    return works, recv, total, pieces
+    return works, recv, total, parts
 
 
-def local_share(send, send_counts, seg_capacity, num_longs, group=None):
-    """The records this rank keeps for itself: a view of its own segment of `send` and their number."""
+def local_share(send, send_counts, seg_capacity, num_longs, group=None, pieces=1):
+    """The records this rank keeps for itself: views of its own pieces of `send` (each from its first word to the end of the
+    buffer) with their units, piece after piece, and the units in all."""
     me = dist.get_rank(group)
-    n = int(send_counts[me])
-    base = me * seg_capacity * num_longs
-    return send[base:base + n * num_longs], n
+    own = []
+    for q in range(pieces):
+        j = me * pieces + q
+        own.append((send[j * seg_capacity * num_longs:], int(send_counts[j])))
+    return own, sum(n for _, n in own)
 
 
-def exchange_records(send, send_counts, recv_counts, seg_capacity, num_longs, recv=None, group=None):
-    """Blocking form of start_exchange: returns (received from the others, their number, own share, its number)."""
-    works, recv, total, _ = start_exchange(send, send_counts, recv_counts, seg_capacity, num_longs, recv, group)
+def exchange_records(send, send_counts, recv_counts, seg_capacity, num_longs, recv=None, group=None, pieces=1):
+    """Blocking form of start_exchange: returns (received from the others, their number, own pieces [(view, units)], their units)."""
+    works, recv, total, _ = start_exchange(send, send_counts, recv_counts, seg_capacity, num_longs, recv, group, pieces=pieces)
     for w in works:
         w.wait()
-    own, n_own = local_share(send, send_counts, seg_capacity, num_longs, group)
+    own, n_own = local_share(send, send_counts, seg_capacity, num_longs, group, pieces)
     return recv, total, own, n_own
 
 
@@ -103,9 +113,12 @@ class ShardedKmerAnalysis:
     `counter` and this class puts it on torch's current stream of `device` (kc_set_stream); without one the caller
     must have done so itself.  The C++ twin (csrc/kc_exchange.hpp) orders its two streams with events instead."""
 
-    def __init__(self, extract, insert, num_longs, seg_capacity, device, group=None, counter=None, reserve=None):
+    def __init__(self, extract, insert, num_longs, seg_capacity, device, group=None, counter=None, reserve=None, pieces=1, insert_pieces=None):
         self.extract, self.insert, self.reserve = extract, insert, reserve
-        self.nl, self.seg = num_longs, seg_capacity
+        # insert_pieces(first piece, stride in units, [units]): the rank's own pieces of the send buffer in one call
+        # (KmerCounter.insert_record_pieces); without it they are inserted one by one
+        self.insert_pieces = insert_pieces
+        self.nl, self.seg, self.pieces = num_longs, seg_capacity, pieces
         self.group = group
         self.world = dist.get_world_size(group)
         self.device = device
@@ -117,7 +130,7 @@ class ShardedKmerAnalysis:
                 torch.cuda.set_stream(stream)
             counter.set_stream(stream.cuda_stream)
             self._stream = stream
-        self.send = [torch.zeros(self.world * seg_capacity * num_longs, dtype=torch.int64, device=device) for _ in range(2)]
+        self.send = [torch.zeros(self.world * pieces * seg_capacity * num_longs, dtype=torch.int64, device=device) for _ in range(2)]
         self.recv = [None, None]
         self.pending = None
         self.i = 0
@@ -134,8 +147,12 @@ class ShardedKmerAnalysis:
             return 0
         works, recv, n, own, n_own, pieces = self.pending
         self.pending = None
-        if n_own:
-            self.insert(own, n_own)  # straight from the send buffer (reused two blocks later at the earliest)
+        if own and self.insert_pieces is not None:  # straight from the send buffer (reused two blocks later at the earliest)
+            self.insert_pieces(own[0][0], self.seg, [u for _, u in own])
+        else:
+            for piece, units in own or []:
+                if units:
+                    self.insert(piece[:units * self.nl], units)
         for w in works:
             w.wait()
         if self.reserve is not None:
@@ -156,17 +173,17 @@ class ShardedKmerAnalysis:
         try:
             counts = self.extract(block, self.send[b], self.seg)
         except Exception as e:  # noqa: BLE001 -- whatever it is, it is re-raised below, after the collective
-            failure, counts = e, [-1] * self.world
+            failure, counts = e, [-1] * (self.world * self.pieces)
         sc_host = torch.as_tensor([int(c) for c in counts], dtype=torch.int64)
         rc = exchange_counts(sc_host.to(self.device), self.group).cpu()  # the one host round trip of a block
         if failure is not None:
             raise failure
         if bool((rc < 0).any()):
             raise RuntimeError("rank(s) %s failed to extract their block" % [int(i) for i in torch.nonzero(rc < 0).flatten()])
-        works, recv, n, pieces = start_exchange(self.send[b], sc_host, rc, self.seg, self.nl, self.recv[b], self.group, self.reserve)
+        works, recv, n, pieces = start_exchange(self.send[b], sc_host, rc, self.seg, self.nl, self.recv[b], self.group, self.reserve, self.pieces)
         if self.reserve is None:
             self.recv[b] = recv
-        own, n_own = (None, 0) if self.reserve is not None else local_share(self.send[b], sc_host, self.seg, self.nl, self.group)
+        own, n_own = (None, 0) if self.reserve is not None else local_share(self.send[b], sc_host, self.seg, self.nl, self.group, self.pieces)
         self._complete()  # the previous block: its transfer has had this block's extraction to finish
         self.pending = (works, recv, n, own, n_own, pieces)
         self.sent += int(sc_host.sum())

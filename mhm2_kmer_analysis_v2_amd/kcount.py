@@ -76,6 +76,7 @@ class KmerCounter:
         self._h = L.kc_create(C.byref(cfg), C.byref(st))
         if not self._h:
             raise _lib.KcError(st.value, "kc_create")
+        self._wire_units = bool(wire_units)
         self.k = kmer_len
         self.nl = L.kc_num_longs(kmer_len)          # words of a k-mer in results, dumps and lookups (the reference's)
         self.rec_nl = L.kc_record_longs(kmer_len)   # words of a record on the shard wire (extract_partition / insert_records)
@@ -148,11 +149,12 @@ class KmerCounter:
         check(lib().kc_submit_seq_block(self._h, p, n, 1 if dev else 0), "kc_submit_seq_block")
 
     def wire_unit(self):
-        """(words, records) of one unit of kc_extract_partition / kc_insert_records: (kc_record_longs, 1) for k-mer records,
-        (3, 4) where a context created with wire_units=True exchanges six-byte records (kc_wire_unit)."""
-        w, r = C.c_int(0), C.c_int(0)
-        check(lib().kc_wire_unit(self._h, C.byref(w), C.byref(r)), "kc_wire_unit")
-        return w.value, r.value
+        """(words, records, pieces) of kc_extract_partition / kc_insert_records: a unit of `words` words holds `records`
+        records, every destination gets `pieces` pieces -- (kc_record_longs, 1, 1) for k-mer records, (3, 4, 2..16) where a
+        context created with wire_units=True exchanges six-byte records (kc_wire_unit)."""
+        w, r, q = C.c_int(0), C.c_int(0), C.c_int(0)
+        check(lib().kc_wire_unit(self._h, C.byref(w), C.byref(r), C.byref(q)), "kc_wire_unit")
+        return w.value, r.value, q.value
 
     def partition_owner(self, kmer_words):
         """the shard kc_extract_partition sends this canonical k-mer to (kc_partition_owner)"""
@@ -162,13 +164,14 @@ class KmerCounter:
         return o.value
 
     def extract_partition(self, bases, quals, offsets, records, seg_capacity, nreads=None):
-        """records: device buffer of rank_n*seg_capacity*unit_words u64 (wire_unit()).  Returns per-shard counts of units."""
+        """records: device buffer of rank_n*pieces*seg_capacity*unit_words u64 (wire_unit()).  Returns the units of every
+        piece, destination after destination."""
         pb, dev = _ptr(bases)
         pq, _ = _ptr(quals)
         po, _ = _ptr(offsets)
         pr, _ = _ptr(records)
         n = (len(offsets) - 1) if nreads is None else nreads
-        counts = np.zeros(self.rank_n, dtype=np.uint64)
+        counts = np.zeros(self.rank_n * (self.wire_unit()[2] if self._wire_units else 1), dtype=np.uint64)
         check(lib().kc_extract_partition(self._h, pb, pq, po, n, 1 if dev else 0, pr, seg_capacity, counts.ctypes.data),
               "kc_extract_partition")
         return counts
@@ -216,6 +219,12 @@ class KmerCounter:
     def insert_records(self, records, n):
         pr, _ = _ptr(records)
         check(lib().kc_insert_records(self._h, pr, n), "kc_insert_records")
+
+    def insert_record_pieces(self, records, piece_stride_units, units):
+        """kc_insert_record_pieces: pieces of `units[j]` units that lie piece_stride_units units apart, from `records` on"""
+        pr, _ = _ptr(records)
+        u = np.ascontiguousarray(units, dtype=np.uint64)
+        check(lib().kc_insert_record_pieces(self._h, pr, int(piece_stride_units), len(u), u.ctypes.data), "kc_insert_record_pieces")
 
     # ---- the single-pass shard flow (ownership by level-1 bucket) ----
     def shard_extract(self, bases, quals, offsets, segments, seg_words, nreads=None):

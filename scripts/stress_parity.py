@@ -85,19 +85,21 @@ for c in range(cases):
             if small and t is not None:
                 t["ovf_capacity"] = 1 << 20
             shards = [pkg.KmerCounter(k, rank_me=r, rank_n=R, max_kmers_buffered=cap, tuning=t, wire_units=wu) for r in range(R)]
-            uw, ur = shards[0].wire_unit()
-            flow = "records(%d shards, unit %d words / %d records%s)" % (R, uw, ur, ", small buffer" if small else "")
+            uw, ur, Q = shards[0].wire_unit()
+            flow = "records(%d shards, unit %d words / %d records, %d pieces%s)" % (R, uw, ur, Q, ", small buffer" if small else "")
             nb = int(rng.integers(2, 7))
             seg = occ // ur + 8192
-            recs = torch.zeros(R * seg * uw, dtype=torch.int64, device="cuda")
+            recs = torch.zeros(R * Q * seg * uw, dtype=torch.int64, device="cuda")
             for piece in range(nb):
                 part = list(range(piece * nreads // nb, (piece + 1) * nreads // nb))
                 if not part:
                     continue
                 bb, qq, oo = O.reads_to_arrays([reads[i] for i in part], [quals[i] for i in part])
                 counts = shards[piece % R].extract_partition(bb, qq, oo, recs, seg)
+                for j in range(R * Q):
+                    if int(counts[j]):
+                        shards[j // Q].insert_records(recs[j * seg * uw:], int(counts[j]))
                 for d in range(R):
-                    shards[d].insert_records(recs[d * seg * uw:], int(counts[d]))
                     shards[d].flush()
             parts = [sh.sorted_results() for sh in shards]
             for sh in shards:

@@ -29,18 +29,19 @@ with pkg.KmerCounter(k, max_elems=est, max_kmers_buffered=int(occ * 1.02) + (1 <
 shards = [pkg.KmerCounter(k, rank_me=r, rank_n=R, max_elems=est // R + (1 << 20), max_kmers_buffered=int(occ / R * 1.1) + (1 << 20), wire_units=True,
                           tuning=dict(p1=1024, p2=1024))  # (the benchmark's fan-outs: six-byte records whatever the size of this run)
           for r in range(R)]
-uw, ur = shards[0].wire_unit()
+uw, ur, Q = shards[0].wire_unit()
 assert (uw, ur) == (3, 4), (uw, ur)
-seg = int(block * (L - k - 1) / R * 1.25) // ur + 8192
-send = torch.zeros(R * seg * uw, dtype=torch.int64, device="cuda")
+seg = int(block * (L - k - 1) / R / Q * 1.3) // ur + 8192  # units per piece
+send = torch.zeros(R * Q * seg * uw, dtype=torch.int64, device="cuda")
 units = 0
 for i, r0 in enumerate(range(0, nreads, block)):
     r1 = min(nreads, r0 + block)
     offs = do[r0:r1 + 1] - do[r0]
     counts = shards[i % R].extract_partition(db[r0 * L:], dq[r0 * L:], offs, send, seg, nreads=r1 - r0)
     units += int(counts.sum())
-    for d in range(R):
-        shards[d].insert_records(send[d * seg * uw:], int(counts[d]))
+    for d in range(R):  # a destination's pieces laid end to end, as an exchange lays what it receives
+        flat = torch.cat([send[(d * Q + q) * seg * uw:(d * Q + q) * seg * uw + int(counts[d * Q + q]) * uw] for q in range(Q)])
+        shards[d].insert_records(flat, flat.numel() // uw)
         shards[d].flush()
 print("shipped %d units = %d slots for %d occurrences" % (units, units * ur, occ), flush=True)
 parts = []

@@ -39,12 +39,13 @@ def test_rccl_exchange_compiles_and_links(tmp_path):
 
 
 @pytest.mark.gpu
-@pytest.mark.parametrize("flow", ["buckets", "records"])
+@pytest.mark.parametrize("flow", ["buckets", "records", "wire-units"])
 @pytest.mark.parametrize("k", [21, 51])
 def test_rccl_exchange_one_rank_matches_oracle(tmp_path, k, flow):
     """the C++ exchange driven like count_kmers + KmerDHT, one-member communicator (the box has one GPU): blocks,
     sizes through RCCL, the receiving side ordered by events; result = the oracle's dump.  Both flows of the class: the
-    single-pass one (a shard owns level-1 buckets) and the records one (hash ownership)."""
+    single-pass one (a shard owns level-1 buckets), the records one (hash ownership) and the records one in wire units
+    (csrc/kc_wire6.hpp: six-byte records at k = 21, k-mer records at k = 51)."""
     exe = build_exchange(tmp_path)
     env = dict(os.environ, KC_EXCHANGE_FLOW=flow)
     rng = np.random.default_rng(78)

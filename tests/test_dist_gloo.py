@@ -76,7 +76,28 @@ def _worker(rank, world, port, k, tmp, flow="records"):
                     send[d * seg * nl:d * seg * nl + len(flat)] = torch.from_numpy(flat)
             return [len(b) for b in bins]
 
+        # stand-in of the records flow in pieces (kc_wire_unit: a destination's records kept apart in Q pieces): piece
+        # d * Q + q of the send buffer; what this rank keeps for itself is inserted piece by piece, what arrives comes
+        # laid end to end
+        Q = 4
+        inserts = []
+
+        def extract_pieces(block, send, seg):
+            bins = make_records([reads[i] for i in block], [quals[i] for i in block], k, world)
+            counts = [0] * (world * Q)
+            for d, recs in enumerate(bins):
+                for q in range(Q):
+                    part = [r for r in recs if int(r[0] >> np.uint64(40)) % Q == q]
+                    assert len(part) <= seg
+                    if part:
+                        flat = np.concatenate(part).astype(np.uint64).view(np.int64)
+                        j = d * Q + q
+                        send[j * seg * nl:j * seg * nl + len(flat)] = torch.from_numpy(flat)
+                        counts[j] = len(part)
+            return counts
+
         def insert(recv, n):
+            inserts.append(n)
             a = recv[:n * nl].numpy().view(np.uint64).reshape(n, nl)
             for row in a:
                 key = row.copy()
@@ -123,6 +144,8 @@ def _worker(rank, world, port, k, tmp, flow="records"):
 
         if flow == "records":
             sk = ShardedKmerAnalysis(extract, insert, nl, seg_capacity=20000, device="cpu")
+        elif flow == "records-pieces":
+            sk = ShardedKmerAnalysis(extract_pieces, insert, nl, seg_capacity=6000, device="cpu", pieces=Q)
         else:
             sk = ShardedKmerAnalysis(shard_extract, shard_commit, 1, seg_capacity=20000 * nl + 1, device="cpu", reserve=shard_reserve)
         for b0 in range(0, len(mine), 50):  # several blocks, the last one ragged
@@ -135,7 +158,7 @@ def _worker(rank, world, port, k, tmp, flow="records"):
         for key in list(table)[::7]:
             kw = np.array(key, dtype=np.uint64)
             assert L.kc_owner(kw.ctypes.data, k, world) == rank
-        assert flow == "records" or all(int((r == -1).sum()) <= 1 for r in reserved)  # every reserved word arrived (one pad word at most)
+        assert flow.startswith("records") or all(int((r == -1).sum()) <= 1 for r in reserved)  # every reserved word arrived (one pad word at most)
         tot = torch.tensor([sk.sent, sk.received], dtype=torch.int64)
         dist.all_reduce(tot)
         assert int(tot[0]) == int(tot[1])  # nothing lost or duplicated in flight
@@ -153,7 +176,7 @@ def _worker(rank, world, port, k, tmp, flow="records"):
         dist.destroy_process_group()
 
 
-@pytest.mark.parametrize("flow", ["records", "single-pass"])
+@pytest.mark.parametrize("flow", ["records", "records-pieces", "single-pass"])
 @pytest.mark.parametrize("k", [21, 51])
 def test_two_rank_exchange_matches_single_rank_oracle(k, flow, tmp_path):
     world = 2

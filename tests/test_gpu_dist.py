@@ -58,10 +58,11 @@ def test_sharded_analysis_over_nccl(nccl_world1, k, tuning, flow):
         if flow == "records":
             sh = ShardedKmerAnalysis(extract, lambda recv, n: kc.insert_records(recv, n), nl, 600 * 150, dev, counter=kc)
         elif flow == "records-wire-units":  # units of four six-byte records at k = 21 (kc_wire_unit), k-mer records at k = 51
-            uw, ur = kc.wire_unit()
-            assert (uw, ur) == ((3, 4) if k == 21 else (nl, 1))
+            uw, ur, Q = kc.wire_unit()
+            assert (uw, ur, Q) == ((3, 4, 8) if k == 21 else (nl, 1, 1))
             units = ur
-            sh = ShardedKmerAnalysis(extract, lambda recv, n: kc.insert_records(recv, n), uw, 600 * 150 // ur + 4096, dev, counter=kc)
+            sh = ShardedKmerAnalysis(extract, lambda recv, n: kc.insert_records(recv, n), uw, 600 * 150 // ur + 4096, dev, counter=kc, pieces=Q,
+                                     insert_pieces=kc.insert_record_pieces if k == 21 else None)
         else:  # kc_shard_extract / kc_shard_reserve / kc_shard_commit: with one member nothing leaves the shard
             sh = ShardedKmerAnalysis.single_pass(kc, shard_extract, 600 * 150 * nl + 2048, dev)
         for r0 in range(0, 4000, 600):  # seven blocks: both buffers are reused several times
@@ -72,7 +73,7 @@ def test_sharded_analysis_over_nccl(nccl_world1, k, tuning, flow):
     if units is None:
         assert sh.sent == sh.received == (wst["kmers_inserted"] if flow == "records" else 0)
     else:  # whole units: the records and a few marker slots
-        assert sh.sent == sh.received and wst["kmers_inserted"] <= sh.sent * units <= wst["kmers_inserted"] + 64 * units
+        assert sh.sent == sh.received and wst["kmers_inserted"] <= sh.sent * units <= wst["kmers_inserted"] + 512 * units
     assert st["kmers_inserted"] == wst["kmers_inserted"]
     for g, w in zip(got, want):
         assert g.shape == w.shape and (g == w).all()

@@ -19,13 +19,15 @@ def union(parts):
     return tuple(np.concatenate([p[i] for p in parts])[order] for i in range(4))
 
 
-def run_flow(reads, quals, k, R, tuning, blocks=3, wire_units=True, **kw):
+def run_flow(reads, quals, k, R, tuning, blocks=3, wire_units=True, together=False, **kw):
+    """blocks of reads rotate over the shards as senders; a destination's pieces are inserted one by one, or (together)
+    laid end to end first, as an exchange lays what it receives"""
     import torch
     shards = [pkg.KmerCounter(k, rank_me=r, rank_n=R, tuning=tuning, wire_units=wire_units, time_kernels=True, **kw) for r in range(R)]
-    uw, ur = shards[0].wire_unit()
+    uw, ur, Q = shards[0].wire_unit()
     worst = sum(max(0, len(r) - k - 1) for r in reads)
-    seg = worst // ur + 8 * 1024  # units: everything to one shard, and a padded run per workgroup round and owner
-    recs = torch.zeros(R * seg * uw, dtype=torch.int64, device="cuda")
+    seg = worst // ur + 8 * 1024  # units per piece: everything to one piece, and a closing pair of marker slots
+    recs = torch.zeros(R * Q * seg * uw, dtype=torch.int64, device="cuda")
     per = (len(reads) + blocks - 1) // blocks
     shipped = 0
     for part in range(blocks):
@@ -35,13 +37,24 @@ def run_flow(reads, quals, k, R, tuning, blocks=3, wire_units=True, **kw):
         bb, qq, oo = arrays(reads[sl], quals[sl])
         sender = shards[part % R]
         counts = sender.extract_partition(bb, qq, oo, recs, seg)
+        assert len(counts) == R * Q
         n_here = sum(max(0, len(r) - k - 1) for r in reads[sl])
-        assert n_here <= int(counts.sum()) * ur <= n_here + 2048 * ur  # whole units: a few marker slots per run
+        assert n_here <= int(counts.sum()) * ur <= n_here + 4096 * ur  # whole units: a few marker slots per run
         shipped += int(counts.sum())
         for d in range(R):
-            shards[d].insert_records(recs[d * seg * uw:], int(counts[d]))
+            pieces = [recs[(d * Q + q) * seg * uw:(d * Q + q) * seg * uw + int(counts[d * Q + q]) * uw] for q in range(Q)]
+            if together == "strided":  # where they lie, in one call (kc_insert_record_pieces)
+                shards[d].insert_record_pieces(recs[d * Q * seg * uw:], seg, [int(counts[d * Q + q]) for q in range(Q)])
+            elif together:
+                flat = torch.cat(pieces)
+                if flat.numel():
+                    shards[d].insert_records(flat, flat.numel() // uw)
+            else:
+                for q in range(Q):
+                    if int(counts[d * Q + q]):
+                        shards[d].insert_records(pieces[q], int(counts[d * Q + q]))
             shards[d].flush()
-    return shards, (uw, ur), shipped
+    return shards, (uw, ur, Q), shipped
 
 
 @pytest.mark.parametrize("R", [1, 2, 3, 8])
@@ -51,8 +64,8 @@ def test_wire_units_flow_matches_the_oracle(R):
     reads, quals = random_reads(rng, 1500, min_len=30, max_len=150, genome_len=4000)
     b, q, offs = arrays(reads, quals)
     want, _, wst = oracle_run(b, q, offs, k)
-    shards, (uw, ur), _ = run_flow(reads, quals, k, R, SHORT)
-    assert (uw, ur) == (3, 4)
+    shards, (uw, ur, Q), _ = run_flow(reads, quals, k, R, SHORT, together={2: "strided", 3: True}.get(R, False))
+    assert (uw, ur) == (3, 4) and Q == 8
     parts = [s.sorted_results() for s in shards]
     assert_same(union(parts), want)
     assert sum(s.stats()["kmers_inserted"] for s in shards) == wst["kmers_inserted"]
@@ -85,16 +98,17 @@ def test_wire_units_default_geometry_and_packed_reads_and_seq_block():
     # seq block: case-masked, '_'-joined
     block = "_".join("".join(c if ord(qc) - 33 >= 20 else c.lower() for c, qc in zip(r, ql)) for r, ql in zip(reads, quals)) + "_"
     shards = [pkg.KmerCounter(k, rank_me=r, rank_n=R, wire_units=True, max_kmers_buffered=1 << 22) for r in range(R)]
-    uw, ur = shards[0].wire_unit()
+    uw, ur, Q = shards[0].wire_unit()
     seg = len(block) // ur + 8 * 1024
-    recs = torch.zeros(R * seg * uw, dtype=torch.int64, device="cuda")
-    counts = np.zeros(R, dtype=np.uint64)
+    recs = torch.zeros(R * Q * seg * uw, dtype=torch.int64, device="cuda")
+    counts = np.zeros(R * Q, dtype=np.uint64)
     blk = np.frombuffer(block.encode(), dtype=np.uint8)
     from mhm2_kmer_analysis_v2_amd.kcount import check
     check(pkg.lib().kc_extract_partition_seq_block(shards[0]._h, blk.ctypes.data, len(blk), 0, recs.data_ptr(), seg, counts.ctypes.data),
               "kc_extract_partition_seq_block")
-    for d in range(R):
-        shards[d].insert_records(recs[d * seg * uw:], int(counts[d]))
+    for j in range(R * Q):
+        if int(counts[j]):
+            shards[j // Q].insert_records(recs[j * seg * uw:], int(counts[j]))
     assert_same(union([s.sorted_results() for s in shards]), want)
     for s in shards:
         s.close()
@@ -107,8 +121,8 @@ def test_without_a_six_byte_geometry_the_flag_changes_nothing():
         reads, quals = random_reads(rng, 600, min_len=40, max_len=150, genome_len=2000)
         b, q, offs = arrays(reads, quals)
         want, _, _ = oracle_run(b, q, offs, k)
-        shards, (uw, ur), _ = run_flow(reads, quals, k, 2, tuning)
-        assert (uw, ur) == (pkg.lib().kc_record_longs(k), 1)
+        shards, (uw, ur, Q), _ = run_flow(reads, quals, k, 2, tuning)
+        assert (uw, ur, Q) == (pkg.lib().kc_record_longs(k), 1, 1)
         parts = [s.sorted_results() for s in shards]
         assert_same(union(parts), want)
         L = pkg.lib()
@@ -127,7 +141,7 @@ def test_wire_units_segment_too_small_is_reported():
     reads, quals = random_reads(rng, 400, min_len=60, max_len=150, genome_len=2000)
     b, q, offs = arrays(reads, quals)
     with pkg.KmerCounter(k, rank_me=0, rank_n=R, tuning=SHORT, wire_units=True) as kc:
-        recs = torch.zeros(R * 16 * 3, dtype=torch.int64, device="cuda")
+        recs = torch.zeros(R * kc.wire_unit()[2] * 16 * 3, dtype=torch.int64, device="cuda")
         with pytest.raises(pkg.KcError) as e:
             kc.extract_partition(b, q, offs, recs, 16)
         assert e.value.status == -6
@@ -148,7 +162,7 @@ def test_wire_units_through_a_buffer_smaller_than_the_input_and_into_the_table()
     for s in shards:
         s.close()
     # one block, larger than the buffer: the table path
-    shards, _, _ = run_flow(reads, quals, k, R, SHORT, blocks=1, max_kmers_buffered=total // R // 4)
+    shards, _, _ = run_flow(reads, quals, k, R, SHORT, blocks=1, together=True, max_kmers_buffered=total // R // 4)
     assert_same(union([s.sorted_results() for s in shards]), want)
     assert any("kc_insert_records_kernel" in s.kernel_times() for s in shards)
     for s in shards:

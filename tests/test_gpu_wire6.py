@@ -188,3 +188,41 @@ def test_records_that_look_like_marker_slots_are_kept():
     assert_same(union([s.sorted_results() for s in shards]), want)
     for s in shards:
         s.close()
+
+
+def test_insert_record_pieces_takes_any_set_of_pieces():
+    """kc_insert_record_pieces: empty pieces between full ones, more pieces than one launch reads, and a context without
+    wire units, where a piece is so many k-mer records"""
+    import torch
+    k = 21
+    rng = np.random.default_rng(2024)
+    reads, quals = random_reads(rng, 1800, min_len=40, max_len=150, genome_len=5000)
+    b, q, offs = arrays(reads, quals)
+    want, _, wst = oracle_run(b, q, offs, k)
+    for wire_units in (True, False):
+        with pkg.KmerCounter(k, tuning=SHORT, wire_units=wire_units) as sender, pkg.KmerCounter(k, tuning=SHORT, wire_units=wire_units) as kc:
+            uw, ur, Q = sender.wire_unit()
+            seg = wst["kmers_inserted"] // ur + 4096
+            recs = torch.zeros(Q * seg * uw, dtype=torch.int64, device="cuda")
+            counts = sender.extract_partition(b, q, offs, recs, seg)
+            # every piece cut into five: forty strided pieces (wire units), some of them empty
+            parts = 5
+            sub = seg // parts // 4 * 4
+            units = []
+            for j in range(Q):
+                left = int(counts[j])
+                for p in range(parts):
+                    n = min(left, sub) if p < parts - 1 else left
+                    assert n <= sub or p == parts - 1
+                    units.append(n)
+                    left -= n
+            assert seg - sub * (parts - 1) >= max(units[parts - 1::parts])
+            # sub-pieces lie `sub` units apart except the last of each piece, which may be longer: hand them over piece by
+            # piece of the sender (five strided sub-pieces each), and once more all at once where the stride allows it
+            for j in range(Q):
+                kc.insert_record_pieces(recs[j * seg * uw:], sub, units[j * parts:(j + 1) * parts])
+            assert_same(kc.sorted_results(), want)
+            assert kc.stats()["kmers_inserted"] == wst["kmers_inserted"]
+            kc.reset()
+            kc.insert_record_pieces(recs, seg, [int(c) for c in counts] + [0, 0, 0])  # trailing empty pieces are skipped
+            assert_same(kc.sorted_results(), want)

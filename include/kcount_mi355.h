@@ -201,6 +201,8 @@ int kc_submit_seq_block(kc_ctx *ctx, const char *seqs, uint64_t len, int on_devi
  * extension codes in the low 6 bits of its last word (left | right<<3; 0-3 =
  * ACGT, 4 = none).  KC_ERR_CAPACITY if a segment would overflow (nothing is lost:
  * the table is untouched, call again with more room).
+ * Contexts created with KC_FLAG_WIRE_UNITS: records, counts and capacities are UNITS in PIECES, and h_counts has an entry
+ * per piece -- see kc_wire_unit below.
  */
 int kc_extract_partition(kc_ctx *ctx, const uint8_t *bases, const uint8_t *quals, const uint64_t *offsets,
                          uint64_t nreads, int on_device, uint64_t *d_records, uint64_t seg_capacity,

@@ -337,10 +337,10 @@ class KmerCounter:
 
     def kernel_times(self, clear=False):
         """{kernel name: (launches, total_ms)} from HIP events on the launch stream (needs time_kernels=True)."""
-        arr = (kc_kernel_time * 16)()
+        arr = (kc_kernel_time * 32)()
         n = C.c_int(0)
-        check(lib().kc_get_kernel_times(self._h, arr, 16, C.byref(n)), "kc_get_kernel_times")
-        out = {arr[i].name.decode(): (int(arr[i].launches), float(arr[i].total_ms)) for i in range(min(n.value, 16))}
+        check(lib().kc_get_kernel_times(self._h, arr, 32, C.byref(n)), "kc_get_kernel_times")
+        out = {arr[i].name.decode(): (int(arr[i].launches), float(arr[i].total_ms)) for i in range(min(n.value, 32))}
         if clear:
             check(lib().kc_clear_kernel_times(self._h), "kc_clear_kernel_times")
         return out

@@ -136,6 +136,9 @@ struct kc_ctx {
   uint64_t h_w6cur[WIRE6_MAX_SHARDS << WIRE6_MAX_LG_PIECES];
   bool l1_dropped;       // earlier buffer-fulls of this pass went through level 2 and left level 1 (bk_light_spill): level 2 holds them
   uint64_t l2_held;      // ... that many records (an upper bound)
+  uint8_t *d_l2snap;     // level 2's state before an instalment that cannot be run again as a whole pass (l2_snapshot)
+  size_t l2snap_bytes;
+  bool l2snap_fresh;     // the snapshot is of a level 2 that had not begun (inc_on was false)
   uint64_t l2_per_bucket;  // records every bucket's part of the level-2 arena has room for while level 2 runs in instalments
   uint64_t expect_base;  // CTR_EXPECT when the buffer was last emptied: what is buffered now is CTR_EXPECT - expect_base
   uint64_t expect_prev;  // CTR_EXPECT after the previous block
@@ -455,6 +458,7 @@ extern "C" void kc_destroy(kc_ctx *c) {
   if (c->arena) (void)hipFree(c->arena);
   if (c->d_ctrs) (void)hipFree(c->d_ctrs);
   if (c->d_w6cur) (void)hipFree(c->d_w6cur);
+  if (c->d_l2snap) (void)hipFree(c->d_l2snap);
   if (c->h_ctrs) (void)hipHostFree(c->h_ctrs);
   if (c->d_tile_first) (void)hipFree(c->d_tile_first);
   if (c->d_out_plan) (void)hipFree(c->d_out_plan);
@@ -2634,6 +2638,61 @@ static int bk_l2_reserve(kc_ctx *c, uint64_t need) {
   return KC_OK;
 }
 
+// An instalment of level 2 behind which level 1 is emptied (bk_light_spill), and the last pass of a context that has done
+// that, cannot be answered by "run the whole pass again" when the region overflow list fills up: level 1 no longer holds
+// every record.  So level 2's state -- the regions' lengths, the buckets' arena marks, how far every level-1 chain has been
+// read, the list's length -- is saved before such a launch (a few MB), and when the launch reports a full list the state
+// is put back, the list grown to what the launch asked for, and the same launch repeated.
+static int l2_snapshot(kc_ctx *c) {
+  const Geom &g = c->gm;
+  const size_t b_cnt2 = (size_t)g.P1 * g.P2 * 4, b_used2 = (size_t)g.P1 * 4, b_done1 = (size_t)g.G * g.P1 * 4, need = b_cnt2 + b_used2 + b_done1 + 8;
+  c->l2snap_fresh = !c->inc_on;
+  if (c->l2snap_fresh) return KC_OK;  // nothing to save: the launch itself starts level 2 from zero
+  if (c->l2snap_bytes < need) {
+    if (c->d_l2snap) HIPCHK(hipFree(c->d_l2snap));
+    c->d_l2snap = nullptr;
+    c->l2snap_bytes = 0;
+    HIPCHK(hipMalloc((void **)&c->d_l2snap, need));
+    c->l2snap_bytes = need;
+  }
+  HIPCHK(hipMemcpyAsync(c->d_l2snap, c->bb.cnt2, b_cnt2, hipMemcpyDeviceToDevice, c->stream));
+  HIPCHK(hipMemcpyAsync(c->d_l2snap + b_cnt2, c->bb.used2, b_used2, hipMemcpyDeviceToDevice, c->stream));
+  HIPCHK(hipMemcpyAsync(c->d_l2snap + b_cnt2 + b_used2, c->bb.done1, b_done1, hipMemcpyDeviceToDevice, c->stream));
+  HIPCHK(hipMemcpyAsync(c->d_l2snap + b_cnt2 + b_used2 + b_done1, c->d_cb + CB_OVF2, 8, hipMemcpyDeviceToDevice, c->stream));
+  return KC_OK;
+}
+// back to the snapshot with a list of at least `need` records (its entries from before the launch kept)
+static int l2_restore_and_grow(kc_ctx *c, uint64_t need, uint64_t kept) {
+  const Geom &g = c->gm;
+  const size_t b_cnt2 = (size_t)g.P1 * g.P2 * 4, b_used2 = (size_t)g.P1 * 4, b_done1 = (size_t)g.G * g.P1 * 4;
+  if (need > c->bb.ovf2_cap) {
+    uint64_t *bigger = nullptr;
+    if (hipMalloc((void **)&bigger, need * (size_t)c->nl * 8) != hipSuccess) {
+      (void)hipGetLastError();
+      snprintf(g_last_error, sizeof(g_last_error), "no memory for a region overflow list of %llu records", (unsigned long long)need);
+      return KC_ERR_OUT_OF_MEMORY;
+    }
+    if (kept) HIPCHK(hipMemcpyAsync(bigger, c->bb.ovf2, kept * (size_t)c->nl * 8, hipMemcpyDeviceToDevice, c->stream));
+    HIPCHK(hipStreamSynchronize(c->stream));
+    HIPCHK(hipFree(c->bb.ovf2));
+    c->bk_bytes += (need - c->bb.ovf2_cap) * (size_t)c->nl * 8;
+    c->bb.ovf2 = bigger;
+    c->bb.ovf2_cap = need;
+    c->bk_held[10] = need * (size_t)c->nl * 8;
+  }
+  if (c->l2snap_fresh) {
+    c->inc_on = false;  // the launch starts level 2 from zero again
+    HIPCHK(hipMemsetAsync(c->d_cb + CB_OVF2, 0, 2 * 8, c->stream));  // OVF2, FATAL (nothing was on the list before level 2 began)
+  } else {
+    HIPCHK(hipMemcpyAsync(c->bb.cnt2, c->d_l2snap, b_cnt2, hipMemcpyDeviceToDevice, c->stream));
+    HIPCHK(hipMemcpyAsync(c->bb.used2, c->d_l2snap + b_cnt2, b_used2, hipMemcpyDeviceToDevice, c->stream));
+    HIPCHK(hipMemcpyAsync(c->bb.done1, c->d_l2snap + b_cnt2 + b_used2, b_done1, hipMemcpyDeviceToDevice, c->stream));
+    HIPCHK(hipMemcpyAsync(c->d_cb + CB_OVF2, c->d_l2snap + b_cnt2 + b_used2 + b_done1, 8, hipMemcpyDeviceToDevice, c->stream));
+    HIPCHK(hipMemsetAsync(c->d_cb + CB_FATAL, 0, 8, c->stream));
+  }
+  return KC_OK;
+}
+
 // The buffer is full and more reads are coming (compact records): level 1's records go through level 2 now, level 1
 // starts again empty, level 2 keeps what it has until the regions are counted.  buffered: records level 1 holds (an upper
 // bound).  KC_ERR_UNSUPPORTED_K: not a geometry this works for (the caller takes the other way).
@@ -2666,15 +2725,23 @@ static int bk_light_spill(kc_ctx *c, uint64_t buffered) {
     c->bb.ovf2_cap = cap;
     c->bk_held[10] = cap * 8;
   }
-  rc = bk_level2_launch<1>(c, true);
+  const uint64_t listed = std::min<uint64_t>(c->h_cb[CB_OVF2], c->bb.ovf2_cap);  // on the list before this instalment
+  rc = l2_snapshot(c);
   if (rc) return rc;
-  rc = sync_cb(c);
-  if (rc) return rc;
-  if (c->h_cb[CB_FATAL]) {
-    snprintf(g_last_error, sizeof(g_last_error),
-             "k-mer buffer: the region overflow list filled up in a pass over a buffer smaller than the input (fatal bits %llu): raise max_kmers_buffered",
-             (unsigned long long)c->h_cb[CB_FATAL]);
-    return KC_ERR_CAPACITY;
+  for (int attempt = 0;; attempt++) {
+    rc = bk_level2_launch<1>(c, true);
+    if (rc) return rc;
+    rc = sync_cb(c);
+    if (rc) return rc;
+    const uint64_t fatal = c->h_cb[CB_FATAL];
+    if (!fatal) break;
+    if (fatal != FATAL_OVF2 || attempt > 0) {
+      snprintf(g_last_error, sizeof(g_last_error), "k-mer buffer: records were lost in an instalment of level 2 (fatal bits %llu)", (unsigned long long)fatal);
+      return KC_ERR_CAPACITY;
+    }
+    // the list was too small for what this instalment's heavy regions spill: the counter kept counting past its end
+    rc = l2_restore_and_grow(c, c->h_cb[CB_OVF2] + c->h_cb[CB_OVF2] / 16 + 4096, c->l2snap_fresh ? 0 : listed);
+    if (rc) return rc;
   }
   // what found no room at level 1 joins the flagged regions' list (as bk_level2_t does at the end of a pass)
   const uint64_t n1 = std::min<uint64_t>(c->h_cb[CB_OVF1], c->bb.ovf1_cap);
@@ -2737,6 +2804,12 @@ static int bk_build_regions(kc_ctx *c) {
           (unsigned long long)c->h_ctrs[CTR_BIN0 + 41], (unsigned long long)c->h_ctrs[CTR_BIN0 + 42], (unsigned long long)c->h_ctrs[CTR_BIN0 + 43]);
   HIPCHK(hipMemsetAsync(c->d_cb + 8, 0, 8 * 8, c->stream));
 #endif
+  uint64_t listed = 0;
+  if (c->l1_dropped) {  // (the last pass of a context whose level 1 has been emptied behind earlier instalments)
+    listed = std::min<uint64_t>(c->h_cb[CB_OVF2], c->bb.ovf2_cap);
+    rc = l2_snapshot(c);
+    if (rc) return rc;
+  }
   for (int attempt = 0;; attempt++) {
     switch (c->nl) {
       case 1: rc = bk_level2_t<1>(c); break;
@@ -2749,10 +2822,14 @@ static int bk_build_regions(kc_ctx *c) {
     if (rc) return rc;
     const uint64_t fatal = c->h_cb[CB_FATAL];
     if (!fatal) break;
-    if (fatal != FATAL_OVF2 || attempt > 0 || c->l1_dropped) {  // (after a light spill level 1 no longer holds every record: no second run)
-      snprintf(g_last_error, sizeof(g_last_error), "k-mer buffer: records were lost building the regions (fatal bits %llu)%s", (unsigned long long)fatal,
-               c->l1_dropped ? ": the region overflow list filled up in a pass over a buffer smaller than the input -- raise max_kmers_buffered" : "");
+    if (fatal != FATAL_OVF2 || attempt > 0) {
+      snprintf(g_last_error, sizeof(g_last_error), "k-mer buffer: records were lost building the regions (fatal bits %llu)", (unsigned long long)fatal);
       return KC_ERR_CAPACITY;
+    }
+    if (c->l1_dropped) {  // level 1 no longer holds every record: back to where this pass began, with a larger list
+      rc = l2_restore_and_grow(c, c->h_cb[CB_OVF2] + c->h_cb[CB_OVF2] / 16 + 4096, c->l2snap_fresh ? 0 : listed);
+      if (rc) return rc;
+      continue;
     }
     // The second overflow list was too small for the regions that outgrew their chains (heavy hitters).  Level 1 is
     // untouched and the counter kept counting past the end, so it says exactly how much room the same pass needs.

@@ -625,3 +625,26 @@ def test_lookup_over_results(k):
         assert (c4 == 0).sum() >= 199
         c5, _, _ = kc.lookup(np.zeros((0, kc.nl), dtype=np.uint64))
         assert len(c5) == 0
+
+
+def test_heavy_regions_through_a_small_buffer_grow_the_overflow_list():
+    """k = 11 has few distinct k-mers, so every region's chain is long and the regions that outgrow theirs fill the
+    region overflow list INSIDE an instalment behind which level 1 is emptied (bk_light_spill) -- level 2's state is put
+    back, the list grown, the instalment run again; the same for the last pass (scripts/stress_parity.py found the case)"""
+    k = 11
+    rng = np.random.default_rng(384)
+    reads, quals = random_reads(rng, 5200, min_len=20, max_len=180, genome_len=10800, err=0.005, n_rate=0.0)
+    b, q, offs = arrays(reads, quals)
+    want, wtable, wst = oracle_run(b, q, offs, k)
+    occ = int(wst["kmers_inserted"])
+    for cap in (40000, occ // 5):
+        with pkg.KmerCounter(k, max_kmers_buffered=cap) as kc:
+            for r0 in range(0, len(reads), 400):
+                bb, qq, oo = arrays(reads[r0:r0 + 400], quals[r0:r0 + 400])
+                kc.submit_reads(bb, qq, oo)
+            gtable = kc.dump_table()
+            got = kc.sorted_results()
+            st = kc.stats()
+        assert_same(got, want)
+        assert (gtable[0] == wtable[0]).all() and (gtable[1] == wtable[1]).all() and (gtable[2] == wtable[2]).all()
+        assert st["kmers_inserted"] == occ

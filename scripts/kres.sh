@@ -7,7 +7,7 @@ sed -E -e '/^\s*(case [23]|default):.*<[234][,>]/d' -e '/case 1:.*<1, FMT_(READS
 /opt/rocm/bin/hipcc -O3 -std=c++17 --offload-arch=gfx950 -fPIC -Wno-unused-function -Wno-return-type -ffp-contract=off -Rpass-analysis=kernel-resource-usage "$@" -c -o /dev/null $TMP 2>&1 | python3 -c "
 import sys,re
 cur=None
-want=('l1_reads_kernelILi1ELi0ELb1ELb0ELi21','l1_reads16_kernelILi0ELb0','l2_split_kernelILi1ELb1ELb1ELb0','l2_rec6_kernelILb0ELb0','count_kernelILi1ELb0ELb1','l1_slots_kernelILi0ELb0ELi21','l2_slots_kernelILb0')
+want=('l1_reads_kernelILi1ELi0ELb1ELb0ELi21','l1_reads16_kernelILi0ELb0','l2_split_kernelILi1ELb1ELb1ELb0','l2_rec6_kernelILb0ELb0','bin16_kernelILi0ELi21','l1_wire6_kernel','count_kernelILi1ELb0ELb1','l1_slots_kernelILi0ELb0ELi21','l2_slots_kernelILb0')
 for l in sys.stdin:
     m=re.search(r'Function Name: (\S+)',l)
     if m: cur=m.group(1); continue

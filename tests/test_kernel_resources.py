@@ -54,6 +54,10 @@ def test_hot_kernels_do_not_spill_vector_registers():
     # level 2 of the benchmark configuration (six-byte level-1 records, k = 21): nothing spilled
     l26 = one("_ZN2kc17kc_l2_rec6_kernelILb0ELb0EE")
     assert l26["vgpr_spill_count"] == 0 and l26["private_segment_fixed_size"] == 0 and l26["vgpr_count"] <= 128, l26
+    # the records flow's two kernels of the six-byte wire record (csrc/kc_wire6.hpp): nothing spilled
+    for name in ("_ZN2kc15kc_bin16_kernelILi0ELi21EE", "_ZN2kc18kc_l1_wire6_kernelE"):
+        w6 = one(name)
+        assert w6["vgpr_spill_count"] == 0 and w6["private_segment_fixed_size"] == 0 and w6["vgpr_count"] <= 128, (name, w6)
     # level 2 of the other short-form compact records: three registers are spilled in the per-BUCKET prologue and epilogue (a pair of
     # zeros and the lane id, four times per workgroup and step), none inside the round loop
     l2 = one("_ZN2kc18kc_l2_split_kernelILi1ELb1ELb1ELb0ELb0EE")

@@ -14,9 +14,13 @@
 //                          kc_shard_commit               per received segment, once the side stream says it has landed
 //                                                        (an event, no host wait on the transfer): read in place by level 2
 //     the rank's own share never moves at all.
-//   RECORDS: k-mer records binned by hash owner (kc_extract_partition), inserted by the receiver's level 1
-//     (kc_insert_records) -- two more passes over every record, but it also works for a context on the global-table path
-//     and its records are what a upcxx::rpc would carry across nodes.
+//   RECORDS: records binned by owner (kc_extract_partition), inserted by the receiver's level 1 (kc_insert_records) -- two
+//     more passes over every record, but every shard uses the whole geometry (a full-size shard at any N), it also works
+//     for a context on the global-table path, and its records are what a upcxx::rpc would carry across nodes.  With
+//     contexts created with KC_FLAG_WIRE_UNITS the records are the library's own (csrc/kc_wire6.hpp: at k=21 units of four
+//     six-byte records of the mixed k-mer, a destination's records in `pieces` pieces by the top bits of their level-1
+//     bucket): a send / receive per piece, what arrives laid piece 0 of every sender first, then piece 1, ..., the rank's
+//     own pieces handed over where they lie (kc_insert_record_pieces).
 //
 // Two send buffers alternate, so block i travels while block i+1 is extracted.  Nothing else is communicated: ownership
 // is a pure function of the k-mer (kc_shard_owner / kc_owner), finalize is per shard.
@@ -24,8 +28,9 @@
 // direction at its peak).  At the rate one GPU's kernels run (50 M reads = 6.4 G records in ~72 ms) the links are what
 // bounds an 8-shard stage if a record travels as its 8-byte word: 7/8 x 6.4 G x 8 B = 44.8 GB per step and shard = 6.4 GB
 // per link = 83 ms.  So the BUCKETS flow ships the compact records of k=21 as FIVE bytes (kc_shard.hpp,
-// SHARD_WIRE_COMPACT: 4.0 GB per link = 52 ms, under the kernels' time and overlapped with it on the side stream); longer
-// k-mers and the RECORDS flow ship whole words (DESIGN.md section 6 has the link budget for N = 2, 4, 8).
+// SHARD_WIRE_COMPACT: 4.0 GB per link = 52 ms, under the kernels' time and overlapped with it on the side stream), the
+// RECORDS flow in wire units SIX (4.8 GB per link = 62 ms under its 86 ms of kernels); longer k-mers ship whole words
+// (DESIGN.md section 6 has the link budget for N = 2, 4, 8).
 //
 // Header-only over the C ABI (include/kcount_mi355.h) and <rccl/rccl.h>; no exceptions (MHM2 calls this inside UPC++
 // progress): every method returns a KC_* status, last_error() has the text.  The Python twin used by bench.py and the

@@ -5,13 +5,17 @@ Replaces the reference's only bulk exchange, the aggregated UPC++ RPC of
 ThreeTierAggrStore::update (src/kcount/kmer_dht.cpp:143-151,247-258), inside the
 node.  Two flows, one protocol (sizes first, then one group of point-to-point transfers):
 
-  single pass (ShardedKmerAnalysis.single_pass, what bench.py runs): a shard owns level-1 BUCKETS (csrc/kc_shard.hpp).
+  single pass (ShardedKmerAnalysis.single_pass; what bench.py runs when a shard's share of the regions holds its k-mers):
+      a shard owns level-1 BUCKETS (csrc/kc_shard.hpp).
       Per block of reads every rank runs its ordinary level-1 pass and packs what other shards own into one wire
       segment per destination (kc_shard_extract); the ranks swap the segment sizes (an N x N all-to-all of int64), then
       the segments, each landing in memory of the receiving context (kc_shard_reserve) where level 2 later reads it in
       place (kc_shard_commit).  A rank's own share never moves.
-  records: k-mer records binned by hash owner (kc_extract_partition), inserted by the receiver's level 1
-      (kc_insert_records): two more passes over every record, but independent of the bucketed path.
+  records (what bench.py runs for full-size shards): records binned by owner (kc_extract_partition), inserted by the
+      receiver's level 1 (kc_insert_records): two more passes over every record, but every shard uses the whole geometry.
+      With wire units (KmerCounter(wire_units=True), csrc/kc_wire6.hpp) the records are the library's own -- at k=21 units
+      of four six-byte records of the mixed k-mer -- and a destination's records come in `pieces` pieces by the top bits
+      of their level-1 bucket: a transfer per piece, what arrives laid piece 0 of every sender first, then piece 1, ...
 
 Nothing else is communicated: ownership is a pure function of the k-mer, finalize is per shard.
 """

@@ -226,3 +226,27 @@ def test_insert_record_pieces_takes_any_set_of_pieces():
             kc.reset()
             kc.insert_record_pieces(recs, seg, [int(c) for c in counts] + [0, 0, 0])  # trailing empty pieces are skipped
             assert_same(kc.sorted_results(), want)
+
+
+def test_a_k_sweep_keeps_the_contexts_and_changes_the_wire():
+    """MHM2's k sweep over the same contexts (kc_reset with a new k): six-byte units at k = 21, k-mer records at 33, units again"""
+    import torch
+    R = 2
+    rng = np.random.default_rng(55)
+    reads, quals = random_reads(rng, 900, min_len=60, max_len=150, genome_len=3000)
+    b, q, offs = arrays(reads, quals)
+    shards = [pkg.KmerCounter(21, rank_me=r, rank_n=R, tuning=dict(p1=1024, p2=256), wire_units=True, max_kmers_buffered=1 << 21) for r in range(R)]
+    for k in (21, 33, 21):
+        want, _, _ = oracle_run(b, q, offs, k)
+        for s in shards:
+            s.reset(k)
+        uw, ur, Q = shards[0].wire_unit()
+        assert (uw, ur, Q) == ((3, 4, 8) if k == 21 else (2, 1, 1))
+        seg = sum(max(0, len(r) - k - 1) for r in reads) // ur + 4096
+        recs = torch.zeros(R * Q * seg * uw, dtype=torch.int64, device="cuda")
+        counts = shards[0].extract_partition(b, q, offs, recs, seg)
+        for d in range(R):
+            shards[d].insert_record_pieces(recs[d * Q * seg * uw:], seg, [int(c) for c in counts[d * Q:(d + 1) * Q]])
+        assert_same(union([s.sorted_results() for s in shards]), want)
+    for s in shards:
+        s.close()

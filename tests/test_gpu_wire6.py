@@ -250,3 +250,29 @@ def test_a_k_sweep_keeps_the_contexts_and_changes_the_wire():
         assert_same(union([s.sorted_results() for s in shards]), want)
     for s in shards:
         s.close()
+
+
+def test_wire_units_from_device_reads_whose_qualities_are_not_co_aligned():
+    """device-resident input at odd addresses: bases and qualities do not share their 16-byte phase (the byte-loading
+    instantiation of the sender, FMT_READS_UQ)"""
+    import torch
+    k, R = 21, 2
+    rng = np.random.default_rng(808)
+    reads, quals = random_reads(rng, 1100, min_len=30, max_len=150, genome_len=3500)
+    b, q, offs = arrays(reads, quals)
+    want, _, _ = oracle_run(b, q, offs, k)
+    db = torch.zeros(len(b) + 64, dtype=torch.uint8, device="cuda")
+    dq = torch.zeros(len(q) + 64, dtype=torch.uint8, device="cuda")
+    db[5:5 + len(b)] = torch.from_numpy(b).cuda()
+    dq[11:11 + len(q)] = torch.from_numpy(q).cuda()
+    do = torch.from_numpy(offs.astype(np.int64)).cuda()
+    shards = [pkg.KmerCounter(k, rank_me=r, rank_n=R, tuning=SHORT, wire_units=True) for r in range(R)]
+    uw, ur, Q = shards[0].wire_unit()
+    seg = sum(max(0, len(r) - k - 1) for r in reads) // ur + 4096
+    recs = torch.zeros(R * Q * seg * uw, dtype=torch.int64, device="cuda")
+    counts = shards[1].extract_partition(db[5:5 + len(b)], dq[11:11 + len(q)], do, recs, seg)
+    for d in range(R):
+        shards[d].insert_record_pieces(recs[d * Q * seg * uw:], seg, [int(c) for c in counts[d * Q:(d + 1) * Q]])
+    assert_same(union([s.sorted_results() for s in shards]), want)
+    for s in shards:
+        s.close()

@@ -779,16 +779,18 @@ static int bk_init(kc_ctx *c) {
     }
   }
   if (g.P1 < 1 || g.P2 < 1 || g.P1 > PMAX || g.P2 > PMAX) return KC_ERR_INVALID_ARG;
-  // six-byte level-1 records: wherever the kernels that write them run -- compact records of k = 21 (MHM2's first and only
-  // one-word k of its default sweep, src/options.hpp:80) whose mix fits 32 bits below the level-1 bucket
+  // six-byte level-1 records: wherever the kernels that write them run -- compact records whose mix fits 32 bits below the
+  // level-1 bucket (k <= 21 with 1024 buckets; k = 21, MHM2's first and only one-word k of its default sweep,
+  // src/options.hpp:80, has instantiations of its own)
   // (KC_L1_ROUND16=0: the general kernels with their rounds of eight and 8-byte records, for A/B runs)
   {
     static const bool round16 = !(getenv("KC_L1_ROUND16") && getenv("KC_L1_ROUND16")[0] == '0');
-    g.rec6 = (c->nl == 1 && g.cp && c->k == 21 && g.k2 - g.la <= 32 && round16) ? 1u : 0u;
+    g.rec6 = (c->nl == 1 && g.cp && g.k2 - g.la <= 32 && round16) ? 1u : 0u;
   }
   // the records flow's wire: units of four six-byte records where level 1 writes those (kc_wire6.hpp), k-mer records otherwise
-  c->wire6 = (c->cfg.flags & KC_FLAG_WIRE_UNITS) && g.rec6 && !(c->cfg.flags & KC_FLAG_REFERENCE_OWNER) && c->cfg.rank_n >= 1 &&
-             c->cfg.rank_n <= (int)WIRE6_MAX_SHARDS;
+  // (the owner's eight bits of the mix, 13..20, must lie below the region's: at least 21 bits of the mix that no region implies)
+  c->wire6 = (c->cfg.flags & KC_FLAG_WIRE_UNITS) && g.rec6 && g.k2 - g.la - g.lb >= 21 && !(c->cfg.flags & KC_FLAG_REFERENCE_OWNER) &&
+             c->cfg.rank_n >= 1 && c->cfg.rank_n <= (int)WIRE6_MAX_SHARDS;
   // one writer per CU, but never so many that a writer's share of the buffer is below a few rounds of records
   g.G = t.writers ? std::min<uint32_t>(t.writers, GMAX)
                   : (uint32_t)std::max<uint64_t>(1, std::min<uint64_t>((uint64_t)std::min<int>(c->num_cus, GMAX), bcap / (4 * 16384)));
@@ -970,7 +972,10 @@ static int launch_l1_reads_t(kc_ctx *c, const ExtractArgs &a, uint64_t nsuper) {
   if constexpr (NL == 1) {
     // ... and its rounds of sixteen k-mers per thread, six-byte records (kc_l1_reads16_kernel; Geom::rec6)
     if (c->gm.rec6) {
-      auto kern16 = sh ? kc_l1_reads16_kernel<FMT, true, 21> : kc_l1_reads16_kernel<FMT, false, 21>;
+      // (k = 21 has an instantiation of its own, with its shift counts and masks as constants; any other k of the short form
+      // runs the same kernel with them in registers)
+      auto kern16 = c->k == 21 ? (sh ? kc_l1_reads16_kernel<FMT, true, 21> : kc_l1_reads16_kernel<FMT, false, 21>)
+                               : (sh ? kc_l1_reads16_kernel<FMT, true, 0> : kc_l1_reads16_kernel<FMT, false, 0>);
       int rc16 = set_dyn_lds(kern16, l1x16_lds_bytes());
       if (rc16) return rc16;
       KernelTimer kt(c, FMT == FMT_READS_UQ ? KT_L1_READS_UQ : KT_L1_READS16);
@@ -1042,7 +1047,7 @@ static uint32_t bin_pieces(const kc_ctx *c) { return 1u << bin_lg_pieces(c); }
 
 template <int FMT>
 static int launch_bin16_t(kc_ctx *c, const ExtractArgs &a, uint64_t nsuper) {
-  auto kern = kc_bin16_kernel<FMT, 21>;
+  auto kern = c->k == 21 ? kc_bin16_kernel<FMT, 21> : kc_bin16_kernel<FMT, 0>;
   int rc = set_dyn_lds(kern, bin16_lds_bytes());
   if (rc) return rc;
   const unsigned grid = (unsigned)std::min<uint64_t>((uint64_t)c->num_cus, nsuper);

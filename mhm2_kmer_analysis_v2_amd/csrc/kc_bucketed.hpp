@@ -554,11 +554,14 @@ __device__ __forceinline__ void l1_overflow(const Geom &gm, const BucketBufs &bb
 // Outputs, in the short register form of split_stage: lo[j] = the low 32 bits of the mixed k-mer (with the bucket, its
 // top la >= 2K - 32 bits, that is all of it), bk[j] = bucket | extension codes << 10, or ~0 where there is no k-mer
 // (a code >= 4 means "none"; here a missing extension keeps the base in its low bits, which every consumer ignores).
-template <int K, int RPOS, bool SH, class TL>
+// (KT = 0: k is the launch's, a.k <= 23 -- the same instructions with their shift counts and masks in scalar registers; the
+// instantiation for MHM2's k = 21 has them as constants)
+template <int KT, int RPOS, bool SH, class TL>
 __device__ __forceinline__ void cp_run_fixed(const TL &L, int lp0, bool active, const Geom &gm, const ExtractArgs &a, uint32_t (&lo)[RPOS],
                                              uint32_t (&bk)[RPOS]) {
-  constexpr int NB = RPOS + K + 1;
-  static_assert(NB <= 32 && RPOS % 8 == 0 && PRE % 8 == 0, "the window must fit one word and never start word-aligned");
+  const int K = KT ? KT : (int)a.k;
+  const int NB = RPOS + K + 1;
+  static_assert(RPOS + KT + 1 <= 32 && RPOS % 8 == 0 && PRE % 8 == 0, "the window must fit one word and never start word-aligned");
   const uint64_t *W = reinterpret_cast<const uint64_t *>(L.codes);
   const uint32_t *OK = reinterpret_cast<const uint32_t *>(L.ok);
   const int p = lp0 - 1, q = p >> 5, s = p & 31;  // lp0 is a multiple of 8: s is 7, 15, 23 or 31, never 0
@@ -568,14 +571,14 @@ __device__ __forceinline__ void cp_run_fixed(const TL &L, int lp0, bool active, 
   const uint32_t nok = ~__builtin_amdgcn_alignbit(ok1, ok0, (uint32_t)s);  // bit i: base i of the window is no extension
   const uint32_t gapw = __builtin_amdgcn_alignbit(g1, g0, (uint32_t)s);    // bit i: read boundary before base i
   const uint64_t Rn = kc_rc_word(Wn) << (64 - 2 * NB);
-  constexpr uint64_t MID = ((1ULL << (2 * K)) - 1ULL) << 2;  // the k-mer inside a slice
-  constexpr uint32_t MK = (1u << K) - 1u;
+  const uint64_t MID = ((1ULL << (2 * K)) - 1ULL) << 2;  // the k-mer inside a slice
+  const uint32_t MK = (1u << K) - 1u;
 #pragma unroll
   for (int j = 0; j < RPOS; j++) {
     const uint64_t x = Wn >> (64 - 2 * (j + K + 2)), y = Rn >> (64 - 2 * (RPOS - 1 - j + K + 2));
     // strict: a palindrome keeps the forward extensions.  An odd k has no palindromes: the k-mers always differ, the right
     // neighbours below them never decide, and only the bases above the slice need masking (one AND per side, not two)
-    constexpr uint64_t CMP = (K & 1) ? (MID | 3ULL) : MID;
+    const uint64_t CMP = (K & 1) ? (MID | 3ULL) : MID;
     const bool swap = (y & CMP) < (x & CMP);
     const uint64_t sel = swap ? y : x;
     // extension codes: the slice's outer bases, bit 2 set where the base may not serve as one
@@ -887,7 +890,7 @@ __device__ __forceinline__ void split_copy_out_pairs(SplitLDS &L, const uint32_t
   constexpr int U = KC_COPY_U;  // pairs per thread and trip: first all their records, then all their destinations, then the stores
   // (D.arena: the owner's part of the level-1 arena in six-byte records, l1_dest6)
   uint8_t *const arena0 = reinterpret_cast<uint8_t *>(D.arena) + ((size_t)D.arena_base << D.log2CH) * 6;
-  const uint32_t shb = 32u - gm.la, shl = 64u - gm.k2;  // (the record as a 64-bit mixed one, for the overflow list only)
+  const uint32_t shb = 64u - gm.la, shl = 64u - gm.k2;  // (the record as a 64-bit mixed one, for the overflow list only)
   for (uint32_t i0 = 2u * (uint32_t)tid; i0 < total; i0 += 2u * U * WGB) {
     uint64_t lo2[U];
     uint32_t bk2[U];
@@ -934,9 +937,10 @@ __device__ __forceinline__ void split_copy_out_pairs(SplitLDS &L, const uint32_t
         const uint32_t j = i - (d[u].z & 0xFFFFu), v = d[u].z >> 16, fit = d[u].w & 0xFFFFu, wold = d[u].w >> 16;
         const uint32_t at0 = (j < wold ? d[u].x : d[u].y) + i, at1 = (j + 1u < wold ? d[u].x : d[u].y) + i + 1u;
         const uint32_t l0 = (uint32_t)lo2[u], l1 = (uint32_t)(lo2[u] >> 32);
-        const uint32_t bh = (bk2[u] & (PMAX - 1)) << shb;
-        const uint64_t ra = ((uint64_t)(bh | (l0 >> (32u - shl))) << 32) | (uint64_t)((l0 << shl) | ((bk2[u] >> 10) & 63u));
-        const uint64_t rb = ((uint64_t)(bh | (l1 >> (32u - shl))) << 32) | (uint64_t)((l1 << shl) | (bk2[u] >> 26));
+        // (where the 32 bits hold some of the bucket's as well -- k < 16 + la / 2 -- the two ORs put the same bits in the same place)
+        const uint64_t bh = (uint64_t)(bk2[u] & (PMAX - 1)) << shb;
+        const uint64_t ra = bh | ((uint64_t)l0 << shl) | (uint64_t)((bk2[u] >> 10) & 63u);
+        const uint64_t rb = bh | ((uint64_t)l1 << shl) | (uint64_t)(bk2[u] >> 26);
         const bool f0 = j < fit, real1 = j + 1u < v, f1 = real1 && j + 1u < fit;
         if (!f0) overflow(ra);
         if (real1 && !(f0 && f1 && at1 == at0 + 1u)) {
